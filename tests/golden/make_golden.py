@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Run in the build container only (``/root/reference`` must be mounted):
+
+    python tests/golden/make_golden.py
+
+What it does: imports ``/root/reference/pyviz/apap.py`` and ``apap_utils.py`` in place
+(nothing is copied), feeds them seeded synthetic inputs, and stores inputs + the
+reference's outputs as small ``.npz`` files.  The committed ``.npz`` files are data; this
+script is how they were made.
+
+Two things the reference needs that this image lacks, and how they are served:
+* ``cv2`` (OpenCV) is not installed.  ``apap.py`` uses exactly one OpenCV function on
+  this path, ``cv.SVDecomp`` (apap.py:160).  An in-memory module object named ``cv2`` is
+  registered whose ``SVDecomp(A)`` returns ``numpy.linalg.svd(A, full_matrices=False)``
+  re-ordered to OpenCV's ``(w, u, vt)``; ``DMatch``/``KeyPoint`` are empty classes because
+  ``utils.py:153`` names them in an annotation at import time.  Consequence, stated in
+  the oracle header and DESIGN.md: parity is unpinned at the bit level of
+  ``cv::SVDecomp`` and pinned mathematically.
+* ``np.int`` (apap_utils.py:59) was removed in numpy 1.24; it was an alias of ``int``
+  and is restored as such for the duration of this script.
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/pyviz"
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    cv2 = types.ModuleType("cv2")
+
+    def SVDecomp(a):
+        u, w, vt = np.linalg.svd(a, full_matrices=False)
+        return w, u, vt
+
+    cv2.SVDecomp = SVDecomp
+    cv2.DMatch = type("DMatch", (), {})
+    cv2.KeyPoint = type("KeyPoint", (), {})
+    sys.modules["cv2"] = cv2
+    if not hasattr(np, "int"):
+        np.int = int
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import apap as ref_apap            # noqa: E402
+        import apap_utils as ref_utils     # noqa: E402
+    finally:
+        os.chdir(cwd)
+    return ref_apap, ref_utils
+
+
+class Shape:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+def tiny_case(ref_apap, ref_utils, sigma, seed, name):
+    """200x140 image, N=120, 5x5 mesh, non-zero offsets in x and y."""
+    rng = np.random.default_rng(seed)
+    W, H, N, m = 200, 140, 120, 5
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    Hg = np.array([[0.97, 0.04, -11.5], [-0.05, 1.03, -7.25], [1.5e-4, -1e-4, 1.0]])
+    src = (rng.random((N, 2)) * [W, H]).astype(np.float32)
+    s = src.astype(np.float64)
+    q = np.concatenate([s, np.ones((N, 1))], axis=1) @ Hg.T
+    dst = (q[:, :2] / q[:, 2:3] + 1.5 * np.sin(s * 9.6 / W) + rng.normal(0, 0.5, (N, 2))).astype(np.float32)
+    gamma = 0.5
+    fw, fh, ox, oy = ref_utils.final_size(Shape(img.shape), Shape(img.shape), Hg)
+    mesh = ref_utils.get_mesh((fw, fh), m + 1)
+    vertices = ref_utils.get_vertice((fw, fh), m, (ox, oy))
+    eng = ref_apap.APAP(gamma, sigma, [fw, fh], [ox, oy])
+    N1, nf1 = eng.getNormalize2DPts(src)
+    N2, nf2 = eng.getNormalize2DPts(dst)
+    C1 = eng.getConditionerFromPts(nf1)
+    C2 = eng.getConditionerFromPts(nf2)
+    cf1 = eng.point_normalize(nf1, C1)
+    cf2 = eng.point_normalize(nf2, C2)
+    aa = eng.matrix_generate(N, cf1, cf2)
+    H_ref, W_ref = eng.local_homography(src, dst, vertices)
+    H_arg = H_ref.copy()
+    warped = eng.local_warp(img, H_arg, mesh, False)       # H_arg now holds the in-place inverses
+    blend_other = rng.integers(0, 256, warped.shape, dtype=np.uint8)
+    blend_other[rng.random(warped.shape[:2]) < 0.3] = 0
+    blended = ref_utils.uniform_blend(warped, blend_other)
+    clamped = float(np.mean(W_ref == gamma))
+    np.savez_compressed(
+        os.path.join(HERE, name), img=img, Hg=Hg, src=src, dst=dst, gamma=gamma, sigma=float(sigma),
+        final=np.array([fw, fh, ox, oy], dtype=np.int64), mesh=mesh, vertices=vertices,
+        N1=N1, N2=N2, C1=C1, C2=C2, nf1=nf1, nf2=nf2, cf1=cf1, cf2=cf2, aa=aa,
+        H_ref=H_ref, W_ref=W_ref, Hinv_ref=H_arg, warped_ref=warped,
+        blend_other=blend_other, blended_ref=blended, seed=seed)
+    print(f"{name}: canvas {fw}x{fh} offsets ({ox},{oy}) clamped fraction {clamped:.3f}")
+
+
+def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16):
+    """A BASELINE.json config: full H grid from the reference; for the warp, a SHA-256 of
+    the full canvas plus every ``warp_rows_every``-th row."""
+    sys.path.insert(0, REPO)
+    from cvx_proj_amd.synth import config_pair
+    p = config_pair(cfg)
+    fw, fh, ox, oy = ref_utils.final_size(Shape(p.shape), Shape(p.shape), p.Hg)
+    assert (fw, fh, ox, oy) == (p.final_w, p.final_h, p.off_x, p.off_y)
+    m = p.vertices.shape[0]
+    assert np.array_equal(ref_utils.get_mesh((fw, fh), m + 1), p.mesh)
+    assert np.array_equal(ref_utils.get_vertice((fw, fh), m, (ox, oy)), p.vertices)
+    eng = ref_apap.APAP(p.gamma, p.sigma, [fw, fh], [ox, oy])
+    H_ref, W_ref = eng.local_homography(p.src, p.dst, p.vertices)
+    out = dict(H_ref=H_ref, final=np.array([fw, fh, ox, oy], dtype=np.int64),
+               W_checksum=np.array([W_ref.sum(), (W_ref * W_ref).sum()]),
+               W_row0=W_ref[0, 0].copy(), W_last=W_ref[-1, -1].copy())
+    del W_ref
+    if warp_rows_every:
+        H_arg = H_ref.copy()
+        warped = eng.local_warp(p.img, H_arg, p.mesh, False)
+        out.update(Hinv_ref=H_arg, warped_rows=warped[::warp_rows_every].copy(),
+                   warp_rows_every=warp_rows_every,
+                   warped_sha256=np.frombuffer(hashlib.sha256(warped.tobytes()).digest(), dtype=np.uint8))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: {cfg} canvas {fw}x{fh} offsets ({ox},{oy}) cells {m}x{m}")
+
+
+def main():
+    ref_apap, ref_utils = import_reference()
+    which = sys.argv[1:] or ["tiny", "C1", "C2"]
+    if "tiny" in which:
+        tiny_case(ref_apap, ref_utils, 100.0, 11, "tiny_sigma100.npz")
+        tiny_case(ref_apap, ref_utils, 6.0, 12, "tiny_sigma6.npz")
+    if "C1" in which:
+        config_case(ref_apap, ref_utils, "C1", "c1_ref.npz", warp_rows_every=8)
+    if "C2" in which:
+        config_case(ref_apap, ref_utils, "C2", "c2_ref.npz", warp_rows_every=0)
+    if "C3" in which:
+        config_case(ref_apap, ref_utils, "C3", "c3_ref.npz", warp_rows_every=0)
+
+
+if __name__ == "__main__":
+    main()
