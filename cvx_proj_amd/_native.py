@@ -1,0 +1,218 @@
+"""ctypes binding of ``libapap_hip.so`` (the C ABI declared in ``include/apap_hip.h``).
+
+This is the whole Python<->native boundary: plain pointers and sizes, no torch types.
+The library is built in-tree by ``cvx_proj_amd/csrc/Makefile`` (see
+``__graft_entry__.build``).  There is no CPU fallback: if the library is missing or no
+gfx950 device is visible, compute calls raise :class:`ApapError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapap_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
+TABLE_STRIDE = 32
+DENORM_DOUBLES = 36
+VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA = 0, 1, 2
+
+
+class ApapError(RuntimeError):
+    """A native call failed; ``code`` is one of the APAP_ERR_* values."""
+
+    def __init__(self, code, message):
+        super().__init__(f"[apap_hip error {code}] {message}")
+        self.code = code
+
+
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes).  Must list every symbol include/apap_hip.h declares;
+# tests/test_capi_symbols.py parses the header and checks this table against it.
+SIGNATURES = {
+    "apap_last_error": (C.c_char_p, []),
+    "apap_version": (C.c_char_p, []),
+    "apap_device_count": (C.c_int, []),
+    "apap_set_solver_variant": (C.c_int, [C.c_int]),
+    "apap_host_prepare": (C.c_int, [_f32p, _f32p, C.c_int] + [_f32p] * 10),
+    "apap_host_dlt_rows": (C.c_int, [_f32p, _f32p, C.c_int, _f32p]),
+    "apap_host_build_table": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, _f64p]),
+    "apap_host_build_denorm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f64p]),
+    "apap_local_homography": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, _f32p, _f64p, C.c_int]),
+    "apap_local_warp": (C.c_int, [_u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
+    "apap_warp_coords": (C.c_int, [_f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, _f64p, C.c_int]),
+    "apap_invert_normalize_flatten": (C.c_int, [_f32p, C.c_int, _f64p, C.c_int]),
+    "apap_uniform_blend": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]),
+    "apap_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "apap_solve_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp,
+                                    C.c_size_t, _vp]),
+    "apap_weights_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp]),
+    "apap_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "apap_warp_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "apap_warp_coords_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "apap_flatten_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "apap_blend_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once.  Raises ApapError (never falls back) if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ApapError(ERR_NO_DEVICE, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; "
+                                           "g.build()'` or `make -C cvx_proj_amd/csrc`")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != OK:
+        raise ApapError(code, lib().apap_last_error().decode("utf-8", "replace"))
+
+
+def last_error():
+    return lib().apap_last_error().decode("utf-8", "replace")
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype)) if a is not None else None
+
+
+def as_f32(a, shape_tail=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_tail is not None and tuple(a.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"expected trailing shape {shape_tail}, got {a.shape}")
+    return a
+
+
+# ------------------------------------------------------------------ host-only helpers
+def host_prepare(src, dst):
+    """C restatement of the set-up in apap.py:132-140,165-166.  Returns a dict of
+    float32 arrays: N1 N2 C1 C2 iC2 iN2 (3x3) and nf1 nf2 cf1 cf2 (n x 2)."""
+    src = as_f32(src, (2,))
+    dst = as_f32(dst, (2,))
+    if src.shape != dst.shape or src.ndim != 2:
+        raise ValueError(f"src/dst must both be (n, 2); got {src.shape} and {dst.shape}")
+    n = src.shape[0]
+    out = {k: np.empty((3, 3), np.float32) for k in ("N1", "N2", "C1", "C2", "iC2", "iN2")}
+    out.update({k: np.empty((n, 2), np.float32) for k in ("nf1", "nf2", "cf1", "cf2")})
+    check(lib().apap_host_prepare(_ptr(src, C.c_float), _ptr(dst, C.c_float), n,
+                                  *[_ptr(out[k], C.c_float) for k in
+                                    ("N1", "N2", "C1", "C2", "iC2", "iN2", "nf1", "nf2", "cf1", "cf2")]))
+    return out
+
+
+def host_dlt_rows(cf1, cf2):
+    cf1 = as_f32(cf1, (2,))
+    cf2 = as_f32(cf2, (2,))
+    n = cf1.shape[0]
+    aa = np.empty((2 * n, 9), np.float32)
+    check(lib().apap_host_dlt_rows(_ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n, _ptr(aa, C.c_float)))
+    return aa
+
+
+def host_build_table(src, cf1, cf2):
+    src = as_f32(src, (2,))
+    cf1 = as_f32(cf1, (2,))
+    cf2 = as_f32(cf2, (2,))
+    n = src.shape[0]
+    table = np.empty((n, TABLE_STRIDE), np.float64)
+    check(lib().apap_host_build_table(_ptr(src, C.c_float), _ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n,
+                                      _ptr(table, C.c_double)))
+    return table
+
+
+def host_build_denorm(iC2, C1, iN2, N1):
+    mats = [as_f32(m, (3, 3)) for m in (iC2, C1, iN2, N1)]
+    out = np.empty(DENORM_DOUBLES, np.float64)
+    check(lib().apap_host_build_denorm(*[_ptr(m, C.c_float) for m in mats], _ptr(out, C.c_double)))
+    return out
+
+
+# ---------------------------------------------------------------- host-buffer compute
+def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device=-1):
+    src = as_f32(src, (2,))
+    dst = as_f32(dst, (2,))
+    if src.ndim != 2 or src.shape != dst.shape:
+        raise ValueError(f"src/dst must both be (n, 2); got {src.shape} and {dst.shape}")
+    vertices = np.ascontiguousarray(vertices, dtype=np.float64)
+    rows, cols, two = vertices.shape      # ValueError on a wrong rank, like apap.py:130
+    if two != 2:
+        raise ValueError(f"vertices must be (rows, cols, 2); got {vertices.shape}")
+    n = src.shape[0]
+    H = np.empty((rows, cols, 3, 3), np.float32)
+    W = np.empty((rows, cols, n), np.float64) if want_weights else None
+    check(lib().apap_local_homography(_ptr(src, C.c_float), _ptr(dst, C.c_float), n, _ptr(vertices, C.c_double),
+                                      rows, cols, float(gamma), float(sigma), _ptr(H, C.c_float),
+                                      _ptr(W, C.c_double), device))
+    return H, W
+
+
+def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=True, device=-1):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    img_h, img_w, ch = img.shape
+    if ch != 3:
+        raise ValueError(f"image must be (h, w, 3); got {img.shape}")
+    H = as_f32(H, (3, 3))
+    rows, cols = H.shape[:2]
+    mesh_w = np.ascontiguousarray(mesh_w, dtype=np.float64)
+    mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
+    out = np.empty((final_h, final_w, 3), np.uint8)
+    Hinv = np.empty_like(H) if want_inverse else None
+    check(lib().apap_local_warp(_ptr(img, C.c_uint8), img_h, img_w, _ptr(H, C.c_float), rows, cols,
+                                _ptr(mesh_w, C.c_double), mesh_w.size, _ptr(mesh_h, C.c_double), mesh_h.size,
+                                int(final_w), int(final_h), int(off_x), int(off_y), _ptr(out, C.c_uint8),
+                                _ptr(Hinv, C.c_float), device))
+    return out, Hinv
+
+
+def warp_coords(H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, device=-1):
+    H = as_f32(H, (3, 3))
+    rows, cols = H.shape[:2]
+    mesh_w = np.ascontiguousarray(mesh_w, dtype=np.float64)
+    mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
+    coords = np.empty((final_h, final_w, 2), np.float64)
+    check(lib().apap_warp_coords(_ptr(H, C.c_float), rows, cols, _ptr(mesh_w, C.c_double), mesh_w.size,
+                                 _ptr(mesh_h, C.c_double), mesh_h.size, int(final_w), int(final_h), int(off_x),
+                                 int(off_y), _ptr(coords, C.c_double), device))
+    return coords
+
+
+def invert_normalize_flatten(H, device=-1):
+    H = as_f32(H, (3, 3))
+    cells = H.size // 9
+    out = np.empty((cells, 9), np.float64)
+    check(lib().apap_invert_normalize_flatten(_ptr(H, C.c_float), cells, _ptr(out, C.c_double), device))
+    return out
+
+
+def uniform_blend(img1, img2, device=-1):
+    a = np.ascontiguousarray(img1, dtype=np.uint8)
+    b = np.ascontiguousarray(img2, dtype=np.uint8)
+    if a.shape != b.shape or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError(f"images must share shape (h, w, 3); got {a.shape} and {b.shape}")
+    out = np.empty_like(a)
+    check(lib().apap_uniform_blend(_ptr(a, C.c_uint8), _ptr(b, C.c_uint8), a.shape[0], a.shape[1],
+                                   _ptr(out, C.c_uint8), device))
+    return out

@@ -1,0 +1,218 @@
+"""Drop-in for the reference's ``pyviz/apap.py``: same class, same methods, same CLI
+and the same ``.mat`` output, with the two hot loops running on an MI355X.
+
+``APAP.local_homography`` (reference apap.py:121-169) and ``APAP.local_warp``
+(apap.py:186-217) call ``libapap_hip.so`` through :mod:`cvx_proj_amd._native`; the small
+static helpers keep their numpy form because they are part of the public surface and
+run once per pair.  There is no CPU fallback for the two loops.
+
+Command line (reference apap.py:220-265 takes ``[case_idx] [img_idx]`` and reads a
+dataset that is not distributed; the positional arguments and the output file are kept,
+the inputs come from ``--pair``)::
+
+    python -m cvx_proj_amd.apap [case_idx] [img_idx] [--pair pair.npz | --synth C1]
+                                [--config configs/case1.txt] [--out-prefix ../diff_1/results/]
+                                [--mesh-size 100] [--gamma 0.5] [--sigma 100] [--warp out.npy]
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+from . import _native
+from .apap_utils import final_size, get_mesh, get_vertice, uniform_blend  # noqa: F401  (re-exported like the reference)
+
+__all__ = ["APAP", "get_mesh", "get_vertice", "final_size", "uniform_blend", "save2mat", "run_pair", "main"]
+
+
+class APAP:
+    """As-Projective-As-Possible moving-DLT engine (GPU).  Constructor and method
+    signatures follow reference apap.py:21-217."""
+
+    def __init__(self, gamma, sigma, final_size, offset, device=-1):
+        self.gamma = gamma
+        self.sigma = sigma
+        self.final_width, self.final_height = final_size
+        self.offset_x, self.offset_y = offset
+        self.device = device
+
+    # ---- once-per-pair helpers: numpy, same arithmetic as the reference -------------
+    @staticmethod
+    def getNormalize2DPts(point):
+        """Similarity that moves the centroid to the origin and the mean distance to
+        sqrt(2); returns ``(t, t . point)``.  Reference apap.py:35-59."""
+        count = point.shape[0]
+        centre = np.mean(point, axis=0)
+        shifted = point - centre
+        mean_dist = np.mean(np.sqrt(np.sum(np.square(shifted), axis=1)))
+        scale = np.sqrt(2) / (mean_dist + 1e-8)
+        t = np.array([[scale, 0, -scale * centre[0]],
+                      [0, scale, -scale * centre[1]],
+                      [0, 0, 1]], dtype=np.float32)
+        homog = np.column_stack((point, np.ones(count, dtype=np.float32)))
+        return t, t.dot(homog.T).T[:, :2]
+
+    @staticmethod
+    def getConditionerFromPts(point):
+        """Per-axis scaling to sample standard deviation sqrt(2).  Reference
+        apap.py:63-89."""
+        count = point.shape[0]
+        mean_x, mean_y = np.mean(point, axis=0)
+        std = np.std(point, axis=0)
+        std_x, std_y = np.sqrt(std * std * count / (count - 1))
+        std_x = std_x + (std_x == 0)
+        std_y = std_y + (std_y == 0)
+        nx, ny = np.sqrt(2) / std_x, np.sqrt(2) / std_y
+        return np.array([[nx, 0, -nx * mean_x], [0, ny, -ny * mean_y], [0, 0, 1]], dtype=np.float32)
+
+    @staticmethod
+    def point_normalize(nf, c):
+        """Apply the diagonal + translation of ``c`` to every point.  Reference
+        apap.py:92-100."""
+        cf = np.zeros_like(nf)
+        cf[:, 0] = nf[:, 0] * c[0, 0] + c[0, 2]
+        cf[:, 1] = nf[:, 1] * c[1, 1] + c[1, 2]
+        return cf
+
+    @staticmethod
+    def matrix_generate(sample_n, cf1, cf2):
+        """The ``2 sample_n x 9`` float32 DLT matrix.  Reference apap.py:103-119."""
+        return _native.host_dlt_rows(np.asarray(cf1)[:sample_n], np.asarray(cf2)[:sample_n])
+
+    @staticmethod
+    def warp_coordinate_estimate(pt, homography):
+        """``homography @ pt`` normalised by its third component.  Reference
+        apap.py:172-184."""
+        target = homography @ pt
+        target /= target[2]
+        return target
+
+    # ---- hot loop 1 ------------------------------------------------------------------
+    def local_homography(self, src_point, dst_point, vertices, return_weights=True):
+        """Per-cell weighted DLT.  Returns ``(H, W)`` like reference apap.py:121-169:
+        ``H`` float32 ``(rows, cols, 3, 3)``, ``W`` float64 ``(rows, cols, n)``.
+
+        ``return_weights=False`` returns ``None`` for ``W``: the tensor costs ``8 n``
+        bytes per cell of HBM and PCIe traffic and the reference's own caller never
+        reads it (apap.py:242)."""
+        return _native.local_homography(src_point, dst_point, vertices, self.gamma, self.sigma,
+                                        want_weights=return_weights, device=self.device)
+
+    # ---- hot loop 2 ------------------------------------------------------------------
+    def local_warp(self, ori_img, local_homography, mesh, progress=False):
+        """Backward warp of ``ori_img`` onto the canvas.  Reference apap.py:186-217.
+
+        Like the reference, the per-cell inverses are written back INTO
+        ``local_homography`` (apap.py:201-203) when it is a writable float32 array.
+        ``progress`` is accepted for signature compatibility; one kernel launch has no
+        rows to report."""
+        mesh_w, mesh_h = mesh
+        ori_h, ori_w, _ = ori_img.shape
+        mesh_n, pt_size, _, _ = local_homography.shape
+        warped, hinv = _native.local_warp(ori_img, local_homography, mesh_w, mesh_h, self.final_width,
+                                          self.final_height, self.offset_x, self.offset_y,
+                                          want_inverse=True, device=self.device)
+        if isinstance(local_homography, np.ndarray) and local_homography.flags.writeable:
+            local_homography[...] = hinv
+        return warped
+
+
+# ------------------------------------------------------------------------------------
+# CLI: apap.py:220-265
+# ------------------------------------------------------------------------------------
+def save2mat(path, arr, name="sift_feature", prefix="./output/"):
+    """Reference utils.py:68-70."""
+    import scipy.io
+    scipy.io.savemat(f"{prefix}{path}.mat", {name: arr})
+
+
+def read_config(path):
+    """``key = value`` lines, the syntax of the reference's configs/case*.txt
+    (options.py:12-13 reads them with configargparse).  Only ``mesh_size``, ``gamma``
+    and ``sigma`` concern this path; the spectral-matching keys are ignored."""
+    out = {}
+    with open(path) as fh:
+        for line in fh:
+            line = line.split("#", 1)[0].strip()
+            if "=" in line:
+                k, v = (s.strip() for s in line.split("=", 1))
+                out[k] = v
+    return out
+
+
+def run_pair(src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
+             other_img=None, device=-1):
+    """Body of the reference's ``__main__`` between loading and saving
+    (apap.py:238-264).  Returns ``(H_flat (m*m, 9) float64, warped or None)``."""
+
+    class _S:
+        def __init__(self, shape):
+            self.shape = shape
+
+    fw, fh, ox, oy = (int(v) for v in final_size(_S(center_shape), _S(other_shape), H_global))
+    mesh = get_mesh((fw, fh), mesh_size + 1)
+    vertices = get_vertice((fw, fh), mesh_size, (ox, oy))
+    eng = APAP(gamma, sigma, [fw, fh], [ox, oy], device=device)
+    H, _ = eng.local_homography(src, dst, vertices, return_weights=False)
+    warped = eng.local_warp(other_img, H.copy(), mesh) if other_img is not None else None
+    flat = _native.invert_normalize_flatten(H, device=device)   # apap.py:250-264
+    return flat, warped
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="cvx_proj_amd.apap", description=__doc__.split("\n\n")[0])
+    ap.add_argument("case_idx", nargs="?", type=int, default=1)
+    ap.add_argument("img_idx", nargs="?", type=int, default=1)
+    ap.add_argument("--pair", help=".npz with src, dst (n,2), H (3,3), other_shape, center_shape[, other_img]")
+    ap.add_argument("--synth", help="use a synthetic configuration of cvx_proj_amd.synth (C1..C5)")
+    ap.add_argument("--config", help="key = value file; mesh_size / gamma / sigma are read")
+    ap.add_argument("--mesh-size", type=int)
+    ap.add_argument("--gamma", type=float)
+    ap.add_argument("--sigma", type=float)
+    ap.add_argument("--out-prefix", default="../diff_1/results/")
+    ap.add_argument("--warp", help="also run local_warp and save the canvas to this .npy")
+    ap.add_argument("--device", type=int, default=-1)
+    a = ap.parse_args(argv)
+
+    par = {"mesh_size": 100, "gamma": 0.5, "sigma": 100.0}     # apap.py:221-223
+    if a.config:
+        cfg = read_config(a.config)
+        for k, cast in (("mesh_size", int), ("gamma", float), ("sigma", float)):
+            if k in cfg:
+                par[k] = cast(cfg[k])
+    for k in par:
+        v = getattr(a, k)
+        if v is not None:
+            par[k] = v
+
+    if a.pair:
+        z = np.load(a.pair)
+        src, dst, Hg = z["src"], z["dst"], z["H"]
+        other_shape, center_shape = tuple(z["other_shape"]), tuple(z["center_shape"])
+        other_img = z["other_img"] if (a.warp and "other_img" in z) else None
+    elif a.synth:
+        from .synth import CONFIGS, synth_pair
+        w, h, n, m, seed = CONFIGS[a.synth]
+        if a.mesh_size is None and not a.config:
+            par["mesh_size"] = m
+        p = synth_pair(w, h, n, par["mesh_size"], seed, with_image=bool(a.warp))
+        src, dst, Hg, other_shape, center_shape, other_img = p.src, p.dst, p.Hg, p.shape, p.shape, p.img
+    else:
+        ap.error("the reference's dataset (../diff_1) is not distributed: give --pair or --synth")
+
+    flat, warped = run_pair(src, dst, Hg, other_shape, center_shape, par["mesh_size"], par["gamma"], par["sigma"],
+                            other_img=other_img, device=a.device)
+    print(f"local_homography shape: {(par['mesh_size'], par['mesh_size'], 3, 3)}")
+    out_dir = f"{a.out_prefix}case{a.case_idx}"
+    os.makedirs(out_dir, exist_ok=True)
+    save2mat(f"case{a.case_idx}/H3{a.img_idx}_apap", flat, name="H", prefix=a.out_prefix)
+    if a.warp and warped is not None:
+        np.save(a.warp, warped)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,278 @@
+// Host-buffer half of the C ABI (include/apap_hip.h): error reporting, device
+// selection, a small grow-only pool of device buffers, and the synchronous entry
+// points that copy caller-owned numpy-style buffers to the GPU, enqueue the kernels
+// through the "_device" entry points and copy the results back.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "apap_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+#define APAP_HIP_TRY(call)                                                              \
+    do {                                                                                \
+        const hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) return apap::fail(APAP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// One pool per process, protected by a mutex: host entry points are serialised (the
+// reference is single-threaded; ctypes releases the GIL, so guard anyway).
+std::mutex g_mu;
+
+struct Slot {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+enum { S_TABLE, S_VERT, S_DENORM, S_H, S_WORK, S_W, S_IMG, S_OUT, S_MESHW, S_MESHH, S_HINV, S_STATUS, S_AUX, S_COUNT };
+Slot g_slots[S_COUNT];
+
+int slot_get(int which, size_t bytes, int dev, void **out) {
+    Slot &s = g_slots[which];
+    if (bytes == 0) bytes = 4;
+    if (s.ptr && (s.cap < bytes || s.dev != dev)) {
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.cap = 0;
+    }
+    if (!s.ptr) {
+        // +16: the warp gather reads one dword at a 3-byte pixel and may touch 1 byte
+        // past the image; keep that inside the allocation for pooled buffers.
+        APAP_HIP_TRY(hipMalloc(&s.ptr, bytes + 16));
+        s.cap = bytes;
+        s.dev = dev;
+    }
+    *out = s.ptr;
+    return APAP_OK;
+}
+
+int select_device(int device, int *chosen) {
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        (void)hipGetLastError();
+        return apap::fail(APAP_ERR_NO_DEVICE,
+                          "no HIP device visible (%s); this engine has no CPU fallback",
+                          e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device >= count) return apap::fail(APAP_ERR_NO_DEVICE, "device %d requested, %d visible", device, count);
+    if (device >= 0) {
+        APAP_HIP_TRY(hipSetDevice(device));
+        *chosen = device;
+    } else {
+        APAP_HIP_TRY(hipGetDevice(chosen));
+    }
+    return APAP_OK;
+}
+
+int status_to_code(int status, const char *who) {
+    if (status & apap::kStatusSingular) return apap::fail(APAP_ERR_SINGULAR, "%s: Singular matrix", who);
+    if (status & apap::kStatusIndex)
+        return apap::fail(APAP_ERR_INDEX, "%s: index 0 is out of bounds for axis 0 with size 0 (mesh edges do not cover the canvas)", who);
+    return APAP_OK;
+}
+
+}  // namespace
+
+namespace apap {
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace apap
+
+extern "C" {
+
+const char *apap_last_error(void) { return g_err; }
+const char *apap_version(void) { return "cvx_proj_amd apap-hip 0.1 (gfx950)"; }
+
+int apap_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
+}
+
+int apap_local_homography(const float *src, const float *dst, int n, const double *vertices,
+                          int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
+                          double *W_out, int device) {
+    if (!src || !dst || !vertices || !H_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: null argument");
+    if (n < 2 || mesh_rows < 1 || mesh_cols < 1)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: n=%d mesh=%dx%d", n, mesh_rows, mesh_cols);
+    if ((long long)mesh_rows * mesh_cols > (1ll << 30)) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: mesh too large");
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev;
+    int rc = select_device(device, &dev);
+    if (rc) return rc;
+
+    // once-per-pair set-up on the host (apap.py:132-145)
+    float N1[9], N2[9], C1[9], C2[9], iC2[9], iN2[9];
+    std::vector<float> cf1((size_t)2 * n), cf2((size_t)2 * n);
+    rc = apap_host_prepare(src, dst, n, N1, N2, C1, C2, iC2, iN2, nullptr, nullptr, cf1.data(), cf2.data());
+    if (rc) return rc;
+    std::vector<double> table((size_t)n * APAP_TABLE_STRIDE);
+    double denorm[APAP_DENORM_DOUBLES];
+    apap_host_build_table(src, cf1.data(), cf2.data(), n, table.data());
+    apap_host_build_denorm(iC2, C1, iN2, N1, denorm);
+
+    const int cells = mesh_rows * mesh_cols;
+    const size_t work_bytes = apap_solve_workspace_bytes(n, cells);
+    void *d_table, *d_vert, *d_denorm, *d_H, *d_work;
+    if ((rc = slot_get(S_TABLE, table.size() * sizeof(double), dev, &d_table))) return rc;
+    if ((rc = slot_get(S_VERT, (size_t)cells * 2 * sizeof(double), dev, &d_vert))) return rc;
+    if ((rc = slot_get(S_DENORM, sizeof(denorm), dev, &d_denorm))) return rc;
+    if ((rc = slot_get(S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
+    if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_vert, vertices, (size_t)cells * 2 * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_denorm, denorm, sizeof(denorm), hipMemcpyHostToDevice, nullptr));
+    rc = apap_solve_device((const double *)d_table, n, (const double *)d_vert, cells, gamma, sigma,
+                           (const double *)d_denorm, (float *)d_H, d_work, work_bytes, nullptr);
+    if (rc) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(H_out, d_H, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    if (W_out) {
+        // stream the weight tensor through a bounded device buffer (it is 8 n bytes per cell)
+        const size_t max_bytes = (size_t)1 << 30;
+        int chunk = (int)(max_bytes / ((size_t)n * sizeof(double)));
+        if (chunk < 1) chunk = 1;
+        if (chunk > cells) chunk = cells;
+        void *d_W;
+        if ((rc = slot_get(S_W, (size_t)chunk * n * sizeof(double), dev, &d_W))) return rc;
+        for (int c0 = 0; c0 < cells; c0 += chunk) {
+            const int nc = cells - c0 < chunk ? cells - c0 : chunk;
+            rc = apap_weights_device((const double *)d_table, n, (const double *)d_vert + (size_t)2 * c0, nc, gamma,
+                                     sigma, (double *)d_W, nullptr);
+            if (rc) return rc;
+            APAP_HIP_TRY(hipMemcpyAsync(W_out + (size_t)c0 * n, d_W, (size_t)nc * n * sizeof(double),
+                                        hipMemcpyDeviceToHost, nullptr));
+            APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+        }
+    }
+    APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    return APAP_OK;
+}
+
+static int warp_common(const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
+                       int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
+                       int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
+                       double *coords, int device, const char *who) {
+    if (!Hfwd || !mesh_w || !mesh_h) return apap::fail(APAP_ERR_INVALID_ARG, "%s: null argument", who);
+    if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
+        return apap::fail(APAP_ERR_INVALID_ARG, "%s: bad size", who);
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev;
+    int rc = select_device(device, &dev);
+    if (rc) return rc;
+    const int cells = mesh_rows * mesh_cols;
+    const size_t work_bytes = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
+    const size_t pixels = (size_t)final_w * final_h;
+    void *d_H, *d_mw, *d_mh, *d_work, *d_status, *d_hinv = nullptr, *d_img = nullptr, *d_out = nullptr;
+    if ((rc = slot_get(S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
+    if ((rc = slot_get(S_MESHW, (size_t)n_w * sizeof(double), dev, &d_mw))) return rc;
+    if ((rc = slot_get(S_MESHH, (size_t)n_h * sizeof(double), dev, &d_mh))) return rc;
+    if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
+    if ((rc = slot_get(S_STATUS, sizeof(int), dev, &d_status))) return rc;
+    if (Hinv_out && (rc = slot_get(S_HINV, (size_t)cells * 9 * sizeof(float), dev, &d_hinv))) return rc;
+    APAP_HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_H, Hfwd, (size_t)cells * 9 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_mw, mesh_w, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_mh, mesh_h, (size_t)n_h * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    if (coords) {
+        if ((rc = slot_get(S_OUT, pixels * 2 * sizeof(double), dev, &d_out))) return rc;
+        rc = apap_warp_coords_device((const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w,
+                                     (const double *)d_mh, n_h, final_w, final_h, off_x, off_y, (double *)d_out,
+                                     d_work, work_bytes, (int *)d_status, nullptr);
+        if (rc) return rc;
+        APAP_HIP_TRY(hipMemcpyAsync(coords, d_out, pixels * 2 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    } else {
+        const size_t img_bytes = (size_t)img_h * img_w * 3;
+        if ((rc = slot_get(S_IMG, img_bytes, dev, &d_img))) return rc;
+        if ((rc = slot_get(S_OUT, pixels * 3, dev, &d_out))) return rc;
+        APAP_HIP_TRY(hipMemcpyAsync(d_img, img, img_bytes, hipMemcpyHostToDevice, nullptr));
+        rc = apap_warp_device((const uint8_t *)d_img, img_h, img_w, (const float *)d_H, mesh_rows, mesh_cols,
+                              (const double *)d_mw, n_w, (const double *)d_mh, n_h, final_w, final_h, off_x, off_y,
+                              (uint8_t *)d_out, (float *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
+        if (rc) return rc;
+        APAP_HIP_TRY(hipMemcpyAsync(out, d_out, pixels * 3, hipMemcpyDeviceToHost, nullptr));
+        if (Hinv_out)
+            APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    }
+    int status = 0;
+    APAP_HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    return status_to_code(status, who);
+}
+
+int apap_local_warp(const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
+                    int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
+                    int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
+                    int device) {
+    if (!img || !out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp: null image");
+    if (img_h < 1 || img_w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp: bad image size");
+    return warp_common(img, img_h, img_w, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h,
+                       off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_warp");
+}
+
+int apap_warp_coords(const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
+                     const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
+                     double *coords, int device) {
+    if (!coords) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_coords: null output");
+    return warp_common(nullptr, 0, 0, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h, off_x,
+                       off_y, nullptr, nullptr, coords, device, "apap_warp_coords");
+}
+
+int apap_invert_normalize_flatten(const float *H, int cells, double *out, int device) {
+    if (!H || !out || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_invert_normalize_flatten: bad argument");
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev;
+    int rc = select_device(device, &dev);
+    if (rc) return rc;
+    void *d_H, *d_out, *d_status;
+    if ((rc = slot_get(S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
+    if ((rc = slot_get(S_AUX, (size_t)cells * 9 * sizeof(double), dev, &d_out))) return rc;
+    if ((rc = slot_get(S_STATUS, sizeof(int), dev, &d_status))) return rc;
+    APAP_HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_H, H, (size_t)cells * 9 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    rc = apap_flatten_device((const float *)d_H, cells, (double *)d_out, (int *)d_status, nullptr);
+    if (rc) return rc;
+    int status = 0;
+    APAP_HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)cells * 9 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    return status_to_code(status, "apap_invert_normalize_flatten");
+}
+
+int apap_uniform_blend(const uint8_t *img1, const uint8_t *img2, int h, int w, uint8_t *out,
+                       int device) {
+    if (!img1 || !img2 || !out || h < 1 || w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_uniform_blend: bad argument");
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev;
+    int rc = select_device(device, &dev);
+    if (rc) return rc;
+    const size_t bytes = (size_t)h * w * 3;
+    void *d_a, *d_b, *d_o;
+    if ((rc = slot_get(S_IMG, bytes, dev, &d_a))) return rc;
+    if ((rc = slot_get(S_AUX, bytes, dev, &d_b))) return rc;
+    if ((rc = slot_get(S_OUT, bytes, dev, &d_o))) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(d_a, img1, bytes, hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_b, img2, bytes, hipMemcpyHostToDevice, nullptr));
+    rc = apap_blend_device((const uint8_t *)d_a, (const uint8_t *)d_b, h, w, (uint8_t *)d_o, nullptr);
+    if (rc) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(out, d_o, bytes, hipMemcpyDeviceToHost, nullptr));
+    APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    return APAP_OK;
+}
+
+}  // extern "C"

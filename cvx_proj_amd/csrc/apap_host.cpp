@@ -1,0 +1,286 @@
+// Host-side set-up of the APAP engine: the once-per-pair arithmetic that the
+// reference's APAP.local_homography performs before its cell loop (apap.py:132-145),
+// restated in C++ with the float32 / float64 roundings numpy applies, so that the
+// numbers handed to the GPU kernels are the ones the reference feeds its own loop.
+//
+// Build note: this file must be compiled with -ffp-contract=off.  Several lines rely
+// on a float32 product being rounded BEFORE the following add (numpy evaluates
+// "a * b + c" as two ufunc calls); a fused multiply-add would change the last bit.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "apap_internal.h"
+
+namespace {
+
+// numpy's float32 add.reduce over a contiguous 1-D array (pairwise summation with
+// an 8-way unrolled leaf of at most 128 elements).  np.mean of a 1-D float32 array
+// uses it (apap.py:49).
+float pairwise_sum_f32(const float *a, long n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int k = 0; k < 8; ++k) r[k] = a[k];
+        long i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
+}
+
+// add.reduce along axis 0 of an (n, 2) C-contiguous float32 array: numpy walks the
+// rows and adds each into the 2-element output, i.e. plain sequential sums.
+void column_sums_f32(const float *p, int n, float &s0, float &s1) {
+    s0 = 0.0f;
+    s1 = 0.0f;
+    for (int i = 0; i < n; ++i) {
+        s0 += p[2 * i];
+        s1 += p[2 * i + 1];
+    }
+}
+
+// numpy divides a float32 sum by the intp count in float64 and casts back.
+inline float div_count(float s, int n) { return (float)((double)s / (double)n); }
+
+// APAP.getNormalize2DPts, apap.py:35-59.
+void normalize_2d_pts(const float *pts, int n, float t[9], float *out) {
+    float s0, s1;
+    column_sums_f32(pts, n, s0, s1);
+    const float c0 = div_count(s0, n), c1 = div_count(s1, n);
+    std::vector<float> dist((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const float dx = pts[2 * i] - c0, dy = pts[2 * i + 1] - c1;
+        const float sx = dx * dx, sy = dy * dy;
+        dist[i] = std::sqrt(sx + sy);
+    }
+    const float mean_dist = div_count(pairwise_sum_f32(dist.data(), n), n);
+    // np.float32 + python float stays float32 (NEP 50); np.sqrt(2) is a float64.
+    const float denom = mean_dist + (float)1e-8;
+    const double scale = std::sqrt(2.0) / (double)denom;
+    for (int k = 0; k < 9; ++k) t[k] = 0.0f;
+    t[0] = (float)scale;
+    t[2] = (float)(-scale * (double)c0);
+    t[4] = (float)scale;
+    t[5] = (float)(-scale * (double)c1);
+    t[8] = 1.0f;
+    if (out) {
+        // t.dot([x, y, 1]^T) in float32 (sgemm): round(round(t00 x) + t02).
+        for (int i = 0; i < n; ++i) {
+            const float px = t[0] * pts[2 * i];
+            const float py = t[4] * pts[2 * i + 1];
+            out[2 * i] = px + t[2];
+            out[2 * i + 1] = py + t[5];
+        }
+    }
+}
+
+// APAP.getConditionerFromPts, apap.py:63-89.  Its argument is the normalised point set
+// of getNormalize2DPts, which numpy hands over as a column-major VIEW
+// (``t.dot(p.T).T[:, :2]``, apap.py:57-58): reductions along axis 0 then run over
+// contiguous memory and use pairwise summation, unlike the row-major keypoint input
+// of getNormalize2DPts.
+void conditioner_from_pts(const float *pts, int n, float T[9]) {
+    std::vector<float> col0((size_t)n), col1((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        col0[i] = pts[2 * i];
+        col1[i] = pts[2 * i + 1];
+    }
+    const float m0 = div_count(pairwise_sum_f32(col0.data(), n), n);
+    const float m1 = div_count(pairwise_sum_f32(col1.data(), n), n);
+    for (int i = 0; i < n; ++i) {
+        const float d0 = col0[i] - m0, d1 = col1[i] - m1;
+        col0[i] = d0 * d0;
+        col1[i] = d1 * d1;
+    }
+    const float q0 = pairwise_sum_f32(col0.data(), n), q1 = pairwise_sum_f32(col1.data(), n);
+    float sd0 = std::sqrt(div_count(q0, n)), sd1 = std::sqrt(div_count(q1, n));
+    // std * std * n / (n - 1), all float32
+    const float fn = (float)n, fn1 = (float)(n - 1);
+    float v0 = sd0 * sd0;
+    v0 = v0 * fn;
+    v0 = v0 / fn1;
+    float v1 = sd1 * sd1;
+    v1 = v1 * fn;
+    v1 = v1 / fn1;
+    float std_x = std::sqrt(v0), std_y = std::sqrt(v1);
+    if (std_x == 0.0f) std_x += 1.0f;
+    if (std_y == 0.0f) std_y += 1.0f;
+    const double norm_x = std::sqrt(2.0) / (double)std_x;
+    const double norm_y = std::sqrt(2.0) / (double)std_y;
+    for (int k = 0; k < 9; ++k) T[k] = 0.0f;
+    T[0] = (float)norm_x;
+    T[2] = (float)(-norm_x * (double)m0);
+    T[4] = (float)norm_y;
+    T[5] = (float)(-norm_y * (double)m1);
+    T[8] = 1.0f;
+}
+
+// APAP.point_normalize, apap.py:92-100.
+void point_normalize(const float *nf, int n, const float c[9], float *cf) {
+    for (int i = 0; i < n; ++i) {
+        const float a = nf[2 * i] * c[0];
+        const float b = nf[2 * i + 1] * c[4];
+        cf[2 * i] = a + c[2];
+        cf[2 * i + 1] = b + c[5];
+    }
+}
+
+}  // namespace
+
+namespace apap {
+
+// numpy.linalg.inv on a float32 3x3 computes in float64 (dgesv: LU with partial
+// pivoting, then two triangular solves against the identity) and casts the result to
+// float32.  Returns false on an exactly-zero pivot (numpy raises LinAlgError).
+bool inv3_f64(const double a_in[9], double out[9]) {
+    double a[3][3], b[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            a[i][j] = a_in[3 * i + j];
+            b[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int k = 0; k < 3; ++k) {
+        int p = k;
+        double best = std::fabs(a[k][k]);
+        for (int i = k + 1; i < 3; ++i)
+            if (std::fabs(a[i][k]) > best) {
+                best = std::fabs(a[i][k]);
+                p = i;
+            }
+        if (a[p][k] == 0.0) return false;
+        if (p != k)
+            for (int j = 0; j < 3; ++j) {
+                std::swap(a[k][j], a[p][j]);
+                std::swap(b[k][j], b[p][j]);
+            }
+        for (int i = k + 1; i < 3; ++i) {
+            const double l = a[i][k] / a[k][k];
+            a[i][k] = 0.0;
+            for (int j = k + 1; j < 3; ++j) a[i][j] -= l * a[k][j];
+            for (int j = 0; j < 3; ++j) b[i][j] -= l * b[k][j];
+        }
+    }
+    for (int j = 0; j < 3; ++j)
+        for (int i = 2; i >= 0; --i) {
+            double s = b[i][j];
+            for (int k = i + 1; k < 3; ++k) s -= a[i][k] * out[3 * k + j];
+            out[3 * i + j] = s / a[i][i];
+        }
+    return true;
+}
+
+bool inv3_f32(const float in[9], float out[9]) {
+    double a[9], r[9];
+    for (int k = 0; k < 9; ++k) a[k] = (double)in[k];
+    if (!inv3_f64(a, r)) return false;
+    for (int k = 0; k < 9; ++k) out[k] = (float)r[k];
+    return true;
+}
+
+}  // namespace apap
+
+extern "C" {
+
+int apap_host_prepare(const float *src, const float *dst, int n, float *N1, float *N2, float *C1,
+                      float *C2, float *iC2, float *iN2, float *nf1, float *nf2, float *cf1,
+                      float *cf2) {
+    if (!src || !dst) return apap::fail(APAP_ERR_INVALID_ARG, "apap_host_prepare: null keypoint array");
+    if (n < 2) return apap::fail(APAP_ERR_INVALID_ARG, "apap_host_prepare: need at least 2 keypoints, got %d", n);
+    float tN1[9], tN2[9], tC1[9], tC2[9], tiC2[9], tiN2[9];
+    std::vector<float> a1((size_t)2 * n), a2((size_t)2 * n), b1((size_t)2 * n), b2((size_t)2 * n);
+    normalize_2d_pts(src, n, tN1, a1.data());
+    normalize_2d_pts(dst, n, tN2, a2.data());
+    conditioner_from_pts(a1.data(), n, tC1);
+    conditioner_from_pts(a2.data(), n, tC2);
+    point_normalize(a1.data(), n, tC1, b1.data());
+    point_normalize(a2.data(), n, tC2, b2.data());
+    if (!apap::inv3_f32(tC2, tiC2)) return apap::fail(APAP_ERR_SINGULAR, "Singular matrix (conditioner C2)");
+    if (!apap::inv3_f32(tN2, tiN2)) return apap::fail(APAP_ERR_SINGULAR, "Singular matrix (normaliser N2)");
+    const size_t m9 = 9 * sizeof(float), pn = (size_t)2 * n * sizeof(float);
+    if (N1) std::memcpy(N1, tN1, m9);
+    if (N2) std::memcpy(N2, tN2, m9);
+    if (C1) std::memcpy(C1, tC1, m9);
+    if (C2) std::memcpy(C2, tC2, m9);
+    if (iC2) std::memcpy(iC2, tiC2, m9);
+    if (iN2) std::memcpy(iN2, tiN2, m9);
+    if (nf1) std::memcpy(nf1, a1.data(), pn);
+    if (nf2) std::memcpy(nf2, a2.data(), pn);
+    if (cf1) std::memcpy(cf1, b1.data(), pn);
+    if (cf2) std::memcpy(cf2, b2.data(), pn);
+    return APAP_OK;
+}
+
+int apap_host_dlt_rows(const float *cf1, const float *cf2, int n, float *aa) {
+    if (!cf1 || !cf2 || !aa || n < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_host_dlt_rows: bad argument");
+    std::memset(aa, 0, (size_t)n * 18 * sizeof(float));
+    for (int k = 0; k < n; ++k) {
+        const float x = cf1[2 * k], y = cf1[2 * k + 1];
+        const float nxp = -cf2[2 * k], nyp = -cf2[2 * k + 1];
+        float *r1 = aa + (size_t)18 * k, *r2 = r1 + 9;
+        r1[0] = x;
+        r1[1] = y;
+        r1[2] = 1.0f;
+        r1[6] = nxp * x;
+        r1[7] = nxp * y;
+        r1[8] = nxp;
+        r2[3] = x;
+        r2[4] = y;
+        r2[5] = 1.0f;
+        r2[6] = nyp * x;
+        r2[7] = nyp * y;
+        r2[8] = nyp;
+    }
+    return APAP_OK;
+}
+
+int apap_host_build_table(const float *src, const float *cf1, const float *cf2, int n,
+                          double *table) {
+    if (!src || !cf1 || !cf2 || !table || n < 1)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_host_build_table: bad argument");
+    for (int k = 0; k < n; ++k) {
+        const float xf = cf1[2 * k], yf = cf1[2 * k + 1];
+        const float nxp = -cf2[2 * k], nyp = -cf2[2 * k + 1];
+        // the float32-rounded DLT entries of apap.py:109-118, widened
+        const double x = xf, y = yf;
+        const double a = (double)(nxp * xf), b = (double)(nxp * yf), c = nxp;
+        const double d = (double)(nyp * xf), e = (double)(nyp * yf), f = nyp;
+        double *t = table + (size_t)APAP_TABLE_STRIDE * k;
+        t[0] = x * x; t[1] = x * y; t[2] = x; t[3] = y * y; t[4] = y; t[5] = 1.0;
+        t[6] = x * a; t[7] = x * b; t[8] = x * c;
+        t[9] = y * a; t[10] = y * b; t[11] = y * c;
+        t[12] = a; t[13] = b; t[14] = c;
+        t[15] = x * d; t[16] = x * e; t[17] = x * f;
+        t[18] = y * d; t[19] = y * e; t[20] = y * f;
+        t[21] = d; t[22] = e; t[23] = f;
+        t[24] = a * a + d * d; t[25] = a * b + d * e; t[26] = a * c + d * f;
+        t[27] = b * b + e * e; t[28] = b * c + e * f; t[29] = c * c + f * f;
+        t[30] = (double)src[2 * k];
+        t[31] = (double)src[2 * k + 1];
+    }
+    return APAP_OK;
+}
+
+int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, const float *N1,
+                           double *denorm) {
+    if (!iC2 || !C1 || !iN2 || !N1 || !denorm)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_host_build_denorm: null argument");
+    for (int k = 0; k < 9; ++k) {
+        denorm[k] = iC2[k];
+        denorm[9 + k] = C1[k];
+        denorm[18 + k] = iN2[k];
+        denorm[27 + k] = N1[k];
+    }
+    return APAP_OK;
+}
+
+}  // extern "C"

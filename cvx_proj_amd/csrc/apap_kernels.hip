@@ -1,0 +1,649 @@
+// gfx950 (MI355X, CDNA4) kernels of the APAP moving-DLT engine and their launchers
+// (the "_device" half of include/apap_hip.h).
+//
+// Data layout in HBM
+//   table     [n][32]  f64   per keypoint: 30 moment products + (src_x, src_y)
+//   vertices  [cells][2] f64 cell sample points
+//   moments   [splits][30][cells_pad] f64  A^T W^2 A of every cell, one slab per
+//                                          keypoint split; SoA so that lanes = cells
+//                                          read and write 512 contiguous bytes
+//   H         [cells][9] f32
+//   Hinv      [cells][12] f32 (padded to 48 B so the warp kernel loads 3 x 16 B)
+//   lut       [final_h + final_w] i32  canvas row -> cell row, canvas column -> cell column
+//
+// Compiled with -ffp-contract=off: every fused multiply-add below is written fma().
+#include <hip/hip_runtime.h>
+
+#include "apap_internal.h"
+
+namespace {
+
+using apap::kMoments;
+constexpr int kWave = 64;
+
+// weight of one keypoint for one cell: max(exp(-|v - s| / sigma^2), gamma), float64 like
+// apap.py:150-152 (np.sqrt and np.exp on float64).
+__device__ __forceinline__ double cell_weight(double vx, double vy, double sx, double sy,
+                                              double inv_sigma, double gamma) {
+    const double dx = vx - sx;
+    const double dy = vy - sy;
+    const double dist = sqrt(dx * dx + dy * dy);
+    const double w = exp(-(dist * inv_sigma));
+    return (w < gamma) ? gamma : w;
+}
+
+// --------------------------------------------------------------------------------
+// K1 (VALU variant): lanes = cells.  A block is 4 waves on the SAME 64 cells; wave s
+// walks keypoints [slice*ppw, slice*ppw + ppw) of the list, slice = 4*blockIdx.y + s.
+// Per keypoint the 32 table doubles are wave-uniform: they arrive through the scalar
+// cache into SGPRs and feed v_fma_f64 as the scalar operand, so the vector unit only
+// executes the weight and 30 FMAs.  The four partial sums are added in LDS in a fixed
+// order (bitwise reproducible), grid-level splits go to separate slabs that K2 adds.
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict__ table, int n,
+                                                       const double *__restrict__ vertices, int cells,
+                                                       int cells_pad, double gamma, double inv_sigma,
+                                                       int pts_per_wave, double *__restrict__ moments) {
+    __shared__ double red[3][kMoments][kWave];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cell = blockIdx.x * kWave + lane;
+    const int cc = min(cell, cells - 1);
+    const double vx = vertices[2 * cc];
+    const double vy = vertices[2 * cc + 1];
+    const int slice = blockIdx.y * 4 + wave;
+    const int p0 = min(n, slice * pts_per_wave);
+    const int p1 = min(n, p0 + pts_per_wave);
+
+    double acc[kMoments];
+#pragma unroll
+    for (int j = 0; j < kMoments; ++j) acc[j] = 0.0;
+
+    for (int p = p0; p < p1; ++p) {
+        const double *__restrict__ row = table + (size_t)p * APAP_TABLE_STRIDE;
+        const double w = cell_weight(vx, vy, row[30], row[31], inv_sigma, gamma);
+        const double w2 = w * w;
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) acc[j] = fma(w2, row[j], acc[j]);
+    }
+
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) red[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double *dst = moments + (size_t)blockIdx.y * kMoments * cells_pad + cell;
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) {
+            double s = acc[j];
+            s += red[0][j][lane];
+            s += red[1][j][lane];
+            s += red[2][j][lane];
+            dst[(size_t)j * cells_pad] = s;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------
+// K2: per-cell symmetric 9x9 eigen-solve by cyclic Jacobi sweeps, lanes = cells, the
+// whole problem (45 + 81 doubles) in registers; then the eigenvector of the smallest
+// eigenvalue is de-normalised (apap.py:161-168) and stored as float32.
+// --------------------------------------------------------------------------------
+__host__ __device__ constexpr int tri(int i, int j) {
+    return i <= j ? i * (19 - i) / 2 + (j - i) : j * (19 - j) / 2 + (i - j);
+}
+
+template <int P, int Q>
+__device__ __forceinline__ void jacobi_rotate(double (&a)[45], double (&v)[81]) {
+    const double apq = a[tri(P, Q)];
+    const double app = a[tri(P, P)];
+    const double aqq = a[tri(Q, Q)];
+    const double theta = 0.5 * (aqq - app) / apq;
+    double t = copysign(1.0, theta) / (fabs(theta) + sqrt(fma(theta, theta, 1.0)));
+    t = (apq != 0.0) ? t : 0.0;  // also discards the NaN of 0/0
+    const double c = 1.0 / sqrt(fma(t, t, 1.0));
+    const double s = t * c;
+    a[tri(P, P)] = fma(-t, apq, app);
+    a[tri(Q, Q)] = fma(t, apq, aqq);
+    a[tri(P, Q)] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (k != P && k != Q) {
+            const double akp = a[tri(k, P)];
+            const double akq = a[tri(k, Q)];
+            a[tri(k, P)] = fma(c, akp, -(s * akq));
+            a[tri(k, Q)] = fma(s, akp, c * akq);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double vkp = v[9 * k + P];
+        const double vkq = v[9 * k + Q];
+        v[9 * k + P] = fma(c, vkp, -(s * vkq));
+        v[9 * k + Q] = fma(s, vkp, c * vkq);
+    }
+}
+
+__device__ __forceinline__ void jacobi_sweep(double (&a)[45], double (&v)[81]) {
+#define APAP_ROW(p, q) jacobi_rotate<p, q>(a, v);
+    APAP_ROW(0, 1) APAP_ROW(0, 2) APAP_ROW(0, 3) APAP_ROW(0, 4) APAP_ROW(0, 5) APAP_ROW(0, 6) APAP_ROW(0, 7) APAP_ROW(0, 8)
+    APAP_ROW(1, 2) APAP_ROW(1, 3) APAP_ROW(1, 4) APAP_ROW(1, 5) APAP_ROW(1, 6) APAP_ROW(1, 7) APAP_ROW(1, 8)
+    APAP_ROW(2, 3) APAP_ROW(2, 4) APAP_ROW(2, 5) APAP_ROW(2, 6) APAP_ROW(2, 7) APAP_ROW(2, 8)
+    APAP_ROW(3, 4) APAP_ROW(3, 5) APAP_ROW(3, 6) APAP_ROW(3, 7) APAP_ROW(3, 8)
+    APAP_ROW(4, 5) APAP_ROW(4, 6) APAP_ROW(4, 7) APAP_ROW(4, 8)
+    APAP_ROW(5, 6) APAP_ROW(5, 7) APAP_ROW(5, 8)
+    APAP_ROW(6, 7) APAP_ROW(6, 8)
+    APAP_ROW(7, 8)
+#undef APAP_ROW
+}
+
+// out = x * y for row-major 3x3, k-ordered FMA chain per element
+__device__ __forceinline__ void mul3(const double *x, const double *y, double *out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            out[3 * i + j] = fma(x[3 * i + 2], y[6 + j], fma(x[3 * i + 1], y[3 + j], x[3 * i] * y[j]));
+}
+
+constexpr int kMaxSweeps = 15;
+
+__global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
+                                                     int cells, int cells_pad,
+                                                     const double *__restrict__ denorm,
+                                                     float *__restrict__ H) {
+    const int cell = blockIdx.x * kWave + threadIdx.x;
+    const int cc = min(cell, cells - 1);
+    double m[kMoments];
+#pragma unroll
+    for (int j = 0; j < kMoments; ++j) {
+        double s = moments[(size_t)j * cells_pad + cc];
+        for (int g = 1; g < splits; ++g) s += moments[((size_t)g * kMoments + j) * cells_pad + cc];
+        m[j] = s;
+    }
+    // A^T W^2 A = [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]  (3x3 blocks)
+    double a[45];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) a[k] = 0.0;
+    a[tri(0, 0)] = m[0]; a[tri(0, 1)] = m[1]; a[tri(0, 2)] = m[2];
+    a[tri(1, 1)] = m[3]; a[tri(1, 2)] = m[4]; a[tri(2, 2)] = m[5];
+    a[tri(3, 3)] = m[0]; a[tri(3, 4)] = m[1]; a[tri(3, 5)] = m[2];
+    a[tri(4, 4)] = m[3]; a[tri(4, 5)] = m[4]; a[tri(5, 5)] = m[5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[tri(i, 6 + j)] = m[6 + 3 * i + j];
+            a[tri(3 + i, 6 + j)] = m[15 + 3 * i + j];
+        }
+    a[tri(6, 6)] = m[24]; a[tri(6, 7)] = m[25]; a[tri(6, 8)] = m[26];
+    a[tri(7, 7)] = m[27]; a[tri(7, 8)] = m[28]; a[tri(8, 8)] = m[29];
+
+    double v[81];
+#pragma unroll
+    for (int k = 0; k < 81; ++k) v[k] = (k % 10 == 0) ? 1.0 : 0.0;
+
+    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+        jacobi_sweep(a, v);
+        double off2 = 0.0, trace = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            trace += fabs(a[tri(i, i)]);
+#pragma unroll
+            for (int j = i + 1; j < 9; ++j) off2 = fma(a[tri(i, j)], a[tri(i, j)], off2);
+        }
+        // quadratic convergence: 1e-17 relative is reached one sweep after ~1e-8.
+        // NaN input never converges and stops at kMaxSweeps.
+        const bool done = off2 <= 1e-34 * trace * trace;
+        if (__all(done)) break;
+    }
+
+    // smallest eigenvalue -> column of V (numpy/OpenCV sort singular values descending
+    // and the reference takes the last row of V^T, apap.py:160-161)
+    int best = 0;
+    double bestv = a[tri(0, 0)];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        const double d = a[tri(i, i)];
+        if (d < bestv) { bestv = d; best = i; }
+    }
+    double h[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double x = v[9 * k];
+#pragma unroll
+        for (int c = 1; c < 9; ++c) x = (best == c) ? v[9 * k + c] : x;
+        h[k] = x;
+    }
+    double t1[9], t2[9];
+    mul3(denorm, h, t1);        // inv(C2) . h
+    mul3(t1, denorm + 9, t2);   // . C1
+    mul3(denorm + 18, t2, t1);  // inv(N2) .
+    mul3(t1, denorm + 27, t2);  // . N1
+    if (cell < cells) {
+        float *out = H + (size_t)cell * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = (float)(t2[k] / t2[8]);
+    }
+}
+
+// --------------------------------------------------------------------------------
+// optional second return value of local_homography: the (cells, n) weight tensor.
+// HBM-write-bound (8 n bytes per cell).
+// --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_weights(const double *__restrict__ table, int n,
+                                                 const double *__restrict__ vertices, int cells,
+                                                 double gamma, double inv_sigma, double *__restrict__ W) {
+    const size_t total = (size_t)cells * n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int cell = (int)(idx / n);
+        const int p = (int)(idx - (size_t)cell * n);
+        const double *row = table + (size_t)p * APAP_TABLE_STRIDE;
+        W[idx] = cell_weight(vertices[2 * cell], vertices[2 * cell + 1], row[30], row[31], inv_sigma, gamma);
+    }
+}
+
+// --------------------------------------------------------------------------------
+// 3x3 inverse in float64 by LU with partial pivoting (what numpy.linalg.inv does for a
+// float32 input: dgesv on the widened matrix, result cast back - apap.py:203,252).
+// Branch-free row swaps so that everything stays in registers.  Returns false on an
+// exactly-zero pivot.
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(bool c, double &x, double &y) {
+    const double tx = c ? y : x, ty = c ? x : y;
+    x = tx;
+    y = ty;
+}
+
+__device__ __forceinline__ bool inv3(const double *m, double *out) {
+    double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[3], a11 = m[4], a12 = m[5], a20 = m[6], a21 = m[7], a22 = m[8];
+    double b00 = 1, b01 = 0, b02 = 0, b10 = 0, b11 = 1, b12 = 0, b20 = 0, b21 = 0, b22 = 1;
+    bool ok = true;
+    // column 0 pivot: first maximal |a_i0|
+    {
+        const bool s1 = fabs(a10) > fabs(a00);
+        cswap(s1, a00, a10); cswap(s1, a01, a11); cswap(s1, a02, a12);
+        cswap(s1, b00, b10); cswap(s1, b01, b11); cswap(s1, b02, b12);
+        const bool s2 = fabs(a20) > fabs(a00);
+        cswap(s2, a00, a20); cswap(s2, a01, a21); cswap(s2, a02, a22);
+        cswap(s2, b00, b20); cswap(s2, b01, b21); cswap(s2, b02, b22);
+        // the two conditional swaps above pick the max but may permute the two
+        // non-pivot rows differently from LAPACK; the inverse does not depend on it
+        // beyond rounding at the 1e-16 level.
+        ok = ok && (a00 != 0.0);
+        const double l1 = a10 / a00, l2 = a20 / a00;
+        a11 = fma(-l1, a01, a11); a12 = fma(-l1, a02, a12);
+        b10 = fma(-l1, b00, b10); b11 = fma(-l1, b01, b11); b12 = fma(-l1, b02, b12);
+        a21 = fma(-l2, a01, a21); a22 = fma(-l2, a02, a22);
+        b20 = fma(-l2, b00, b20); b21 = fma(-l2, b01, b21); b22 = fma(-l2, b02, b22);
+    }
+    {
+        const bool s = fabs(a21) > fabs(a11);
+        cswap(s, a11, a21); cswap(s, a12, a22);
+        cswap(s, b10, b20); cswap(s, b11, b21); cswap(s, b12, b22);
+        ok = ok && (a11 != 0.0);
+        const double l = a21 / a11;
+        a22 = fma(-l, a12, a22);
+        b20 = fma(-l, b10, b20); b21 = fma(-l, b11, b21); b22 = fma(-l, b12, b22);
+    }
+    ok = ok && (a22 != 0.0);
+    // back substitution, column by column
+    const double x20 = b20 / a22, x21 = b21 / a22, x22 = b22 / a22;
+    const double x10 = fma(-a12, x20, b10) / a11, x11 = fma(-a12, x21, b11) / a11, x12 = fma(-a12, x22, b12) / a11;
+    const double x00 = fma(-a02, x20, fma(-a01, x10, b00)) / a00;
+    const double x01 = fma(-a02, x21, fma(-a01, x11, b01)) / a00;
+    const double x02 = fma(-a02, x22, fma(-a01, x12, b02)) / a00;
+    out[0] = x00; out[1] = x01; out[2] = x02;
+    out[3] = x10; out[4] = x11; out[5] = x12;
+    out[6] = x20; out[7] = x21; out[8] = x22;
+    return ok;
+}
+
+// per-cell inverse for the warp (apap.py:201-203): padded float32 copy for the warp
+// kernel, optional dense copy for the caller (the reference's mutated argument).
+__global__ __launch_bounds__(256) void k_invert_cells(const float *__restrict__ H, int cells,
+                                                      float *__restrict__ hinv_pad,
+                                                      float *__restrict__ hinv_dense, int *status) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells) return;
+    double m[9], r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
+    if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
+    float *p = hinv_pad + (size_t)cell * APAP_HINV_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p[k] = (float)r[k];
+    p[9] = p[10] = p[11] = 0.0f;
+    if (hinv_dense) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (float)r[k];
+    }
+}
+
+// canvas row -> cell row and canvas column -> cell column:
+// "first k with i < edges[k]" minus one (apap.py:207,209-210), -1 wrapping to the last
+// cell like a Python index.  No monotonicity is assumed, hence the linear scan.
+__global__ __launch_bounds__(256) void k_cell_lut(const double *__restrict__ mesh_w, int n_w,
+                                                  const double *__restrict__ mesh_h, int n_h,
+                                                  int mesh_rows, int mesh_cols, int final_w,
+                                                  int final_h, int *__restrict__ lut, int *status) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= final_h + final_w) return;
+    const bool is_row = t < final_h;
+    const int idx = is_row ? t : t - final_h;
+    const double *edges = is_row ? mesh_h : mesh_w;
+    const int n_e = is_row ? n_h : n_w;
+    const int ncell = is_row ? mesh_rows : mesh_cols;
+    int first = -1;
+    const double x = (double)idx;
+    for (int k = 0; k < n_e; ++k) {
+        if (x < edges[k]) { first = k; break; }
+    }
+    int c = first - 1;
+    bool bad = first < 0;
+    if (c < 0) c += ncell;
+    bad = bad || c < 0 || c >= ncell;
+    if (bad) { atomicOr(status, apap::kStatusIndex); c = 0; }
+    lut[t] = c;
+}
+
+struct __attribute__((packed, aligned(4))) Bytes12 {
+    unsigned int a, b, c;
+};
+
+// target coordinate of canvas pixel (i, j) through the (already inverted) cell matrix:
+// float64 FMA chain in the order h0*x + h1*y + h2, then two true divisions
+// (apap.py:172-184,211-213: float32 H^-1 promoted to float64 by the int64 point).
+__device__ __forceinline__ void target_of(const float *__restrict__ hinv_pad, int cell, double x,
+                                          double y, double &tx, double &ty) {
+    const float4 *hp = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+    const float4 r0 = hp[0], r1 = hp[1], r2 = hp[2];
+    const double t0 = fma((double)r0.z, 1.0, fma((double)r0.y, y, (double)r0.x * x));
+    const double t1 = fma((double)r1.y, 1.0, fma((double)r1.x, y, (double)r0.w * x));
+    const double t2 = fma((double)r2.x, 1.0, fma((double)r1.w, y, (double)r1.z * x));
+    tx = t0 / t2;
+    ty = t1 / t2;
+}
+
+__device__ __forceinline__ unsigned int gather_rgb(const uint8_t *__restrict__ img, int img_w,
+                                                   int img_h, size_t img_bytes, double tx, double ty) {
+    // strict inequalities and truncation, apap.py:214-215; NaN fails every comparison
+    if (!(0.0 < tx && tx < (double)img_w && 0.0 < ty && ty < (double)img_h)) return 0u;
+    const int ix = (int)tx, iy = (int)ty;
+    const size_t o = ((size_t)iy * img_w + ix) * 3;
+    unsigned int v;
+    if (o + 4 <= img_bytes) {
+        __builtin_memcpy(&v, img + o, 4);  // one unaligned dword
+        return v & 0x00ffffffu;
+    }
+    v = (unsigned int)img[o] | ((unsigned int)img[o + 1] << 8) | ((unsigned int)img[o + 2] << 16);
+    return v;
+}
+
+// K3: backward warp.  One thread = 4 consecutive canvas pixels in flat order = 12
+// contiguous output bytes = one global_store_dwordx3; a wave writes 768 contiguous
+// bytes.  The gather reads 3 bytes per pixel; neighbouring lanes read neighbouring
+// source pixels because local homographies are close to the global one.
+__global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, int img_h, int img_w,
+                                              const float *__restrict__ hinv_pad, int mesh_cols,
+                                              const int *__restrict__ lut, int final_w, int final_h,
+                                              int off_x, int off_y, uint8_t *__restrict__ out) {
+    const size_t total = (size_t)final_w * final_h;
+    const size_t img_bytes = (size_t)img_h * img_w * 3;
+    const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (g >= total) return;
+    int i = (int)(g / final_w);
+    int j = (int)(g - (size_t)i * final_w);
+    unsigned int px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        px[k] = 0u;
+        if (g + k < total) {
+            const int cell = lut[i] * mesh_cols + lut[final_h + j];
+            double tx, ty;
+            target_of(hinv_pad, cell, (double)(j - off_x), (double)(i - off_y), tx, ty);
+            px[k] = gather_rgb(img, img_w, img_h, img_bytes, tx, ty);
+        }
+        if (++j == final_w) { j = 0; ++i; }
+    }
+    uint8_t *o = out + g * 3;
+    if (g + 4 <= total) {
+        Bytes12 v;
+        v.a = px[0] | (px[1] << 24);
+        v.b = (px[1] >> 8) | (px[2] << 16);
+        v.c = (px[2] >> 16) | (px[3] << 8);
+        *reinterpret_cast<Bytes12 *>(o) = v;
+    } else {
+        for (int k = 0; k < 4 && g + k < total; ++k) {
+            o[3 * k] = (uint8_t)(px[k] & 0xff);
+            o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
+            o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
+        }
+    }
+}
+
+// coordinates only (parity tests of the arithmetic of k_warp)
+__global__ __launch_bounds__(256) void k_warp_coords(const float *__restrict__ hinv_pad, int mesh_cols,
+                                                     const int *__restrict__ lut, int final_w,
+                                                     int final_h, int off_x, int off_y,
+                                                     double *__restrict__ coords) {
+    const size_t total = (size_t)final_w * final_h;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int i = (int)(g / final_w);
+    const int j = (int)(g - (size_t)i * final_w);
+    const int cell = lut[i] * mesh_cols + lut[final_h + j];
+    double tx, ty;
+    target_of(hinv_pad, cell, (double)(j - off_x), (double)(i - off_y), tx, ty);
+    coords[2 * g] = tx;
+    coords[2 * g + 1] = ty;
+}
+
+// output stage, apap.py:250-264
+__global__ __launch_bounds__(256) void k_flatten(const float *__restrict__ H, int cells,
+                                                 double *__restrict__ out, int *status) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= cells) return;
+    double m[9], r[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
+    if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
+    float f[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = (float)r[k];
+    const float d = f[8];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) f[k] = f[k] / d;  // float32 division like numpy's in-place /=
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(size_t)cell * 9 + 3 * c + rr] = (double)f[3 * rr + c];
+}
+
+// uniform_blend, apap_utils.py:75-88
+__global__ __launch_bounds__(256) void k_blend(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                               size_t pixels, uint8_t *__restrict__ out) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels;
+         p += (size_t)gridDim.x * blockDim.x) {
+        const uint8_t *pa = a + 3 * p, *pb = b + 3 * p;
+        const unsigned a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        const bool both = (a0 + a1 + a2 > 0) && (b0 + b1 + b2 > 0);
+        const unsigned sh = both ? 1u : 0u;
+        // float64 sum times 0.5 (both non-black) or 1, then astype(uint8) = truncation.
+        // When the factor is 1 one side is all zero, so the sum never exceeds 255.
+        out[3 * p] = (uint8_t)((a0 + b0) >> sh);
+        out[3 * p + 1] = (uint8_t)((a1 + b1) >> sh);
+        out[3 * p + 2] = (uint8_t)((a2 + b2) >> sh);
+    }
+}
+
+inline int hip_fail(hipError_t e, const char *what) {
+    return apap::fail(APAP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+int g_variant = APAP_VARIANT_AUTO;
+
+}  // namespace
+
+namespace apap {
+
+SolvePlan plan_solve(int n, int cells, int variant) {
+    SolvePlan p{};
+    if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_VALU;
+    p.variant = variant;
+    p.cell_tiles = (cells + kWave - 1) / kWave;
+    p.cells_pad = p.cell_tiles * kWave;
+    // Fill the chip: 256 CUs x 4 SIMDs; aim at >= 2 waves per SIMD.  A block already
+    // splits the keypoints 4 ways; add grid-level splits for small meshes, but keep
+    // at least 64 keypoints per wave.
+    int splits = 1;
+    const int want_waves = 2048;
+    while (splits < 16 && p.cell_tiles * 4 * splits < want_waves && n / (4 * splits * 2) >= 64) splits *= 2;
+    p.splits = splits;
+    p.pts_per_wave = (n + 4 * splits - 1) / (4 * splits);
+    p.moment_bytes = (size_t)splits * kMoments * p.cells_pad * sizeof(double);
+    return p;
+}
+
+}  // namespace apap
+
+extern "C" {
+
+int apap_set_solver_variant(int variant) {
+    const int prev = g_variant;
+    if (variant == APAP_VARIANT_AUTO || variant == APAP_VARIANT_VALU || variant == APAP_VARIANT_MFMA) g_variant = variant;
+    return prev;
+}
+
+size_t apap_solve_workspace_bytes(int n, int cells) {
+    if (n < 1 || cells < 1) return 0;
+    // both variants use the same slab geometry; size for the larger split count
+    return apap::plan_solve(n, cells, g_variant).moment_bytes;
+}
+
+int apap_solve_device(const double *d_table, int n, const double *d_vertices, int cells,
+                      double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
+                      size_t work_bytes, void *stream) {
+    if (!d_table || !d_vertices || !d_denorm || !d_H || !d_work)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: null device pointer");
+    if (n < 1 || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: n=%d cells=%d", n, cells);
+    const apap::SolvePlan p = apap::plan_solve(n, cells, g_variant);
+    if (work_bytes < p.moment_bytes)
+        return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes, p.moment_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    const double inv_sigma = 1.0 / (sigma * sigma);  // apap.py:142
+    double *moments = (double *)d_work;
+    hipLaunchKernelGGL(k_assemble_valu, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
+                       cells, p.cells_pad, gamma, inv_sigma, p.pts_per_wave, moments);
+    hipLaunchKernelGGL(k_eigen_denorm, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
+                       p.cells_pad, d_denorm, d_H);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
+    return APAP_OK;
+}
+
+int apap_weights_device(const double *d_table, int n, const double *d_vertices, int cells,
+                        double gamma, double sigma, double *d_W, void *stream) {
+    if (!d_table || !d_vertices || !d_W) return apap::fail(APAP_ERR_INVALID_ARG, "apap_weights_device: null device pointer");
+    if (n < 1 || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_weights_device: n=%d cells=%d", n, cells);
+    const size_t total = (size_t)cells * n;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_weights, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_table, n, d_vertices, cells,
+                       gamma, 1.0 / (sigma * sigma), d_W);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_weights_device launch");
+    return APAP_OK;
+}
+
+size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h) {
+    if (mesh_rows < 1 || mesh_cols < 1 || final_w < 1 || final_h < 1) return 0;
+    const size_t hinv = (size_t)mesh_rows * mesh_cols * APAP_HINV_STRIDE * sizeof(float);
+    const size_t lut = ((size_t)final_w + final_h) * sizeof(int);
+    return ((hinv + 255) / 256) * 256 + ((lut + 255) / 256) * 256;
+}
+
+static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
+                         int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
+                         float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
+                         hipStream_t s, float **hinv_pad, int **lut) {
+    if (!d_Hfwd || !d_mesh_w || !d_mesh_h || !d_work || !d_status)
+        return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
+    if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
+        return apap::fail(APAP_ERR_INVALID_ARG, "warp: bad size");
+    const size_t need = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
+    if (work_bytes < need) return apap::fail(APAP_ERR_WORKSPACE, "warp: workspace %zu < %zu bytes", work_bytes, need);
+    const int cells = mesh_rows * mesh_cols;
+    const size_t hinv_bytes = (((size_t)cells * APAP_HINV_STRIDE * sizeof(float) + 255) / 256) * 256;
+    *hinv_pad = (float *)d_work;
+    *lut = (int *)((char *)d_work + hinv_bytes);
+    hipLaunchKernelGGL(k_invert_cells, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+                       d_Hinv_out, d_status);
+    hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
+                       d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
+    return APAP_OK;
+}
+
+int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+                     int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
+                     int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
+                     float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
+                     void *stream) {
+    if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
+    if (img_h < 1 || img_w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size");
+    hipStream_t s = (hipStream_t)stream;
+    float *hinv_pad;
+    int *lut;
+    const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
+                                 d_Hinv_out, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
+    if (rc != APAP_OK) return rc;
+    const size_t total = (size_t)final_w * final_h;
+    const size_t threads = (total + 3) / 4;
+    hipLaunchKernelGGL(k_warp, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_img, img_h, img_w,
+                       hinv_pad, mesh_cols, lut, final_w, final_h, off_x, off_y, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
+    return APAP_OK;
+}
+
+int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
+                            int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
+                            int off_x, int off_y, double *d_coords, void *d_work, size_t work_bytes,
+                            int *d_status, void *stream) {
+    if (!d_coords) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_coords_device: null output");
+    hipStream_t s = (hipStream_t)stream;
+    float *hinv_pad;
+    int *lut;
+    const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
+                                 nullptr, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
+    if (rc != APAP_OK) return rc;
+    const size_t total = (size_t)final_w * final_h;
+    hipLaunchKernelGGL(k_warp_coords, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hinv_pad, mesh_cols,
+                       lut, final_w, final_h, off_x, off_y, d_coords);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_warp_coords_device launch");
+    return APAP_OK;
+}
+
+int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_status, void *stream) {
+    if (!d_H || !d_out || !d_status) return apap::fail(APAP_ERR_INVALID_ARG, "apap_flatten_device: null device pointer");
+    if (cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_flatten_device: cells=%d", cells);
+    hipLaunchKernelGGL(k_flatten, dim3((cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_H, cells, d_out,
+                       d_status);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_flatten_device launch");
+    return APAP_OK;
+}
+
+int apap_blend_device(const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream) {
+    if (!d_a || !d_b || !d_out || h < 1 || w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_blend_device: bad argument");
+    const size_t pixels = (size_t)h * w;
+    const int blocks = (int)((pixels + 255) / 256 < 16384 ? (pixels + 255) / 256 : 16384);
+    hipLaunchKernelGGL(k_blend, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_a, d_b, pixels, d_out);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_blend_device launch");
+    return APAP_OK;
+}
+
+}  // extern "C"

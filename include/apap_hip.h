@@ -1,0 +1,178 @@
+/*
+ * apap_hip.h - C ABI of libapap_hip.so, the MI355X (gfx950) engine for the APAP
+ * moving-DLT path of Enigmatisms/cvx_proj.
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python surface
+ * of class APAP in pyviz/apap.py and the helpers of pyviz/apap_utils.py, consumed only
+ * by apap.py's __main__ (apap.py:238-265).  Every entry point below names the
+ * reference interface it stands in for.  A maintainer binds them with ctypes; the
+ * binding is shown in INTEGRATION.md and shipped as cvx_proj_amd/_native.py.
+ *
+ * Conventions
+ *  - Plain C types only.  All arrays are row-major and caller-owned; the library
+ *    never keeps a pointer after a call returns.
+ *  - Every function that returns int returns APAP_OK (0) or one of the APAP_ERR_*
+ *    codes; apap_last_error() then gives a thread-local human-readable message.
+ *    The reference signals the same conditions with Python exceptions
+ *    (numpy.linalg.LinAlgError from apap.py:165-166,203; IndexError from
+ *    apap.py:207,209-210; ValueError from the shape unpacking at apap.py:129-130).
+ *  - "Host" entry points take host pointers and are synchronous: inputs are copied
+ *    to the selected GPU, the kernels run, outputs are copied back before return.
+ *  - "_device" entry points take DEVICE pointers (hipMalloc'ed by the caller, or a
+ *    torch tensor's data_ptr()) and a hipStream_t passed as void* (NULL = the
+ *    default stream).  They only enqueue work; the caller synchronises.  They are
+ *    what bench.py and the multi-GPU driver use to keep data resident in HBM.
+ *  - There is no CPU fallback.  Without a usable gfx950 device every compute entry
+ *    point fails with APAP_ERR_NO_DEVICE.
+ */
+#ifndef APAP_HIP_H
+#define APAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APAP_OK 0
+#define APAP_ERR_INVALID_ARG 1 /* bad pointer / size (reference: ValueError on unpack)       */
+#define APAP_ERR_NO_DEVICE 2   /* no HIP device, or device index out of range                */
+#define APAP_ERR_HIP 3         /* a HIP runtime call failed; message has hipGetErrorString   */
+#define APAP_ERR_SINGULAR 4    /* exact-zero pivot in a 3x3 inverse (reference: LinAlgError) */
+#define APAP_ERR_INDEX 5       /* mesh edges do not cover the canvas (reference: IndexError) */
+#define APAP_ERR_WORKSPACE 6   /* caller-provided workspace too small                        */
+
+/* Doubles per keypoint in the device point table (see apap_host_build_table). */
+#define APAP_TABLE_STRIDE 32
+/* Doubles in the de-normalisation block: inv(C2), C1, inv(N2), N1 (3x3 row-major each). */
+#define APAP_DENORM_DOUBLES 36
+/* Floats per cell in the padded inverse-homography buffer the warp kernel reads. */
+#define APAP_HINV_STRIDE 12
+
+/* Solver variants (apap_set_solver_variant).  Both produce the same numbers up to
+ * the summation order of the 30 moment sums. */
+#define APAP_VARIANT_AUTO 0
+#define APAP_VARIANT_VALU 1 /* one lane per cell, fp64 FMA accumulation            */
+#define APAP_VARIANT_MFMA 2 /* v_mfma_f64_16x16x4_f64 accumulation, table via LDS  */
+
+/* ---------------------------------------------------------------- diagnostics --- */
+const char *apap_last_error(void);
+const char *apap_version(void);
+/* Number of visible HIP devices; 0 when there is none (never an error). */
+int apap_device_count(void);
+/* Select the assembly kernel; returns the previous value.  Process-wide. */
+int apap_set_solver_variant(int variant);
+
+/* ------------------------------------------------------------ host-only helpers --- */
+/* No GPU needed.  They restate, in C and in float32 exactly as numpy evaluates the
+ * reference, the once-per-pair set-up that APAP.local_homography performs before its
+ * cell loop. */
+
+/* APAP.getNormalize2DPts x2, getConditionerFromPts x2, point_normalize x2
+ * (apap.py:35-100,133-140) and the two float32 inverses of apap.py:165-166.
+ * src, dst: n x 2 float32.  Outputs (any may be NULL): N1,N2,C1,C2,iC2,iN2 are 3x3
+ * float32 row-major; nf1,nf2,cf1,cf2 are n x 2 float32. */
+int apap_host_prepare(const float *src, const float *dst, int n, float *N1, float *N2, float *C1,
+                      float *C2, float *iC2, float *iN2, float *nf1, float *nf2, float *cf1,
+                      float *cf2);
+
+/* APAP.matrix_generate (apap.py:103-119): the 2n x 9 float32 DLT matrix. */
+int apap_host_dlt_rows(const float *cf1, const float *cf2, int n, float *aa);
+
+/* Device point table: per keypoint APAP_TABLE_STRIDE doubles -
+ *   [0..29]  the 30 distinct entries of r1 r1^T + r2 r2^T, r1/r2 being the point's two
+ *            float32 DLT rows (products of float32 values are exact in float64),
+ *   [30,31]  the source keypoint (x, y) widened to float64.
+ * and the 36-double de-normalisation block. */
+int apap_host_build_table(const float *src, const float *cf1, const float *cf2, int n,
+                          double *table);
+int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, const float *N1,
+                           double *denorm);
+
+/* ------------------------------------------------------ host-buffer entry points --- */
+
+/* APAP.local_homography (apap.py:121-169).
+ *   src, dst   n x 2 float32 keypoints (src -> dst)
+ *   vertices   mesh_rows x mesh_cols x 2 float64 cell sample points
+ *   gamma,sigma  the two scalars of APAP.__init__ (apap.py:22-32)
+ *   H_out      mesh_rows x mesh_cols x 9 float32
+ *   W_out      NULL, or mesh_rows x mesh_cols x n float64 (the reference's second
+ *              return value; 8*n bytes per cell of extra HBM + PCIe traffic)
+ *   device     HIP device index, or -1 for the current device */
+int apap_local_homography(const float *src, const float *dst, int n, const double *vertices,
+                          int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
+                          double *W_out, int device);
+
+/* APAP.local_warp (apap.py:186-217).
+ *   img        img_h x img_w x 3 uint8
+ *   Hfwd       mesh_rows x mesh_cols x 9 float32; inverted per cell inside, like
+ *              apap.py:201-203 does in place
+ *   mesh_w/h   cell edges along x / y (the two rows of get_mesh), n_w / n_h entries
+ *   out        final_h x final_w x 3 uint8
+ *   Hinv_out   NULL, or mesh_rows x mesh_cols x 9 float32 receiving the inverses (what
+ *              the reference leaves in its mutated argument) */
+int apap_local_warp(const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
+                    int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
+                    int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
+                    int device);
+
+/* Same inputs as apap_local_warp; writes the float64 target coordinates (tx, ty) of
+ * every canvas pixel (apap.py:211-213) instead of gathering.  coords: final_h x
+ * final_w x 2 float64.  For parity tests of the coordinate arithmetic. */
+int apap_warp_coords(const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
+                     const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
+                     double *coords, int device);
+
+/* Output stage of apap.py:250-264: per cell H <- inv(H), H /= H[2,2] (float32), then
+ * the transposed 3x3 flattened to 9 float64.  H: cells x 9 float32; out: cells x 9. */
+int apap_invert_normalize_flatten(const float *H, int cells, double *out, int device);
+
+/* uniform_blend (apap_utils.py:75-88) over two h x w x 3 uint8 canvases. */
+int apap_uniform_blend(const uint8_t *img1, const uint8_t *img2, int h, int w, uint8_t *out,
+                       int device);
+
+/* -------------------------------------------------- resident (device) entry points --- */
+
+/* Bytes of scratch apap_solve_device needs for this problem size. */
+size_t apap_solve_workspace_bytes(int n, int cells);
+
+/* Per-cell weighted DLT + eigen-solve + de-normalisation on resident data.
+ *   d_table    n x APAP_TABLE_STRIDE doubles   (apap_host_build_table)
+ *   d_vertices cells x 2 doubles
+ *   d_denorm   APAP_DENORM_DOUBLES doubles     (apap_host_build_denorm)
+ *   d_H        cells x 9 floats (output)
+ *   d_work     scratch of apap_solve_workspace_bytes(n, cells) bytes */
+int apap_solve_device(const double *d_table, int n, const double *d_vertices, int cells,
+                      double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
+                      size_t work_bytes, void *stream);
+
+/* The weights tensor alone: d_W cells x n doubles. */
+int apap_weights_device(const double *d_table, int n, const double *d_vertices, int cells,
+                        double gamma, double sigma, double *d_W, void *stream);
+
+size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h);
+
+/* Backward warp on resident data.  d_status: one int the kernels OR error bits into
+ * (bit 0: singular cell, bit 1: index error); zero it before the call.  d_Hinv_out
+ * may be NULL. */
+int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+                     int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
+                     int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
+                     float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
+                     void *stream);
+
+/* Coordinates-only twin of apap_warp_device (d_coords: final_h x final_w x 2 doubles). */
+int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
+                            int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
+                            int off_x, int off_y, double *d_coords, void *d_work, size_t work_bytes,
+                            int *d_status, void *stream);
+
+int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_status, void *stream);
+
+int apap_blend_device(const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APAP_HIP_H */

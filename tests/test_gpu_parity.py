@@ -1,0 +1,289 @@
+"""Parity of the HIP engine with the reference (golden vectors) and the oracle, through
+the C ABI.  Run on the GPU box: ``python -m pytest tests -m gpu``.
+
+Tolerances (BASELINE.json north_star):
+* per-cell homographies: reprojection-RMSE delta < 1e-4 px versus the reference, where
+  the delta of a cell is the RMS over keypoints of |proj(H_gpu, p) - proj(H_ref, p)|;
+* warp coordinates within 1 ULP of float32; warped pixels compared exactly, every
+  differing pixel must sit on an integer boundary of the reference coordinate.
+"""
+import numpy as np
+import pytest
+
+from oracle import apap_oracle as O
+from cvx_proj_amd.apap import APAP
+from cvx_proj_amd.synth import config_pair, synth_pair
+from conftest import ulp_diff_f32
+
+pytestmark = pytest.mark.gpu
+
+RMSE_BAR = 1e-4          # px, north_star
+TINY = ["tiny_sigma100", "tiny_sigma6"]
+VARIANTS = [1, 2]        # APAP_VARIANT_VALU, APAP_VARIANT_MFMA
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(native):
+    assert native.lib().apap_device_count() >= 1, "these tests need a GPU; the library found none"
+
+
+@pytest.fixture(params=VARIANTS, ids=["valu", "mfma"])
+def variant(request, native):
+    prev = native.lib().apap_set_solver_variant(request.param)
+    yield request.param
+    native.lib().apap_set_solver_variant(prev)
+
+
+def report(tag, H, H_ref, pts):
+    d = O.reprojection_rmse_delta(H, H_ref, pts)
+    print(f"[{tag}] rmse-delta max {d.max():.3e} px, float32 values differing "
+          f"{int((H != H_ref).sum())}/{H.size}, max ulp {int(ulp_diff_f32(H, H_ref).max())}")
+    return d
+
+
+# ------------------------------------------------------------------ hot loop 1
+@pytest.mark.parametrize("name", TINY)
+def test_tiny_homography_vs_reference(native, golden, variant, name):
+    g = golden(name)
+    H, W = native.local_homography(g["src"], g["dst"], g["vertices"], float(g["gamma"]), float(g["sigma"]))
+    assert H.shape == g["H_ref"].shape and H.dtype == np.float32
+    d = report(name, H, g["H_ref"], g["src"])
+    assert d.max() < RMSE_BAR
+    # the weight tensor: same formula in float64; device exp/sqrt are within 2 ulp
+    assert W.shape == g["W_ref"].shape
+    assert np.allclose(W, g["W_ref"], rtol=1e-15 * 8, atol=0)
+    clamp_ref = g["W_ref"] == g["gamma"]
+    assert np.mean((W == g["gamma"]) != clamp_ref) < 1e-3
+
+
+@pytest.mark.parametrize("cfg,name", [("C1", "c1_ref"), ("C2", "c2_ref"), ("C3", "c3_ref")])
+def test_config_grid_vs_reference(native, golden, variant, cfg, name):
+    g = golden(name)
+    p = config_pair(cfg, with_image=False)
+    H, W = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    assert W is None
+    d = report(cfg, H, g["H_ref"], p.src[:128])
+    assert d.max() < RMSE_BAR
+    assert np.mean(H != g["H_ref"]) < 0.01      # in practice bit-identical almost everywhere
+
+
+def test_weights_checksum_c2(native, golden):
+    g = golden("c2_ref")
+    p = config_pair("C2", with_image=False)
+    _, W = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=True)
+    assert np.allclose([W.sum(), (W * W).sum()], g["W_checksum"], rtol=1e-13)
+    assert np.allclose(W[0, 0], g["W_row0"], rtol=1e-14) and np.allclose(W[-1, -1], g["W_last"], rtol=1e-14)
+
+
+@pytest.mark.parametrize("rows,cols,n", [(1, 1, 4), (3, 7, 5), (9, 2, 64), (65, 1, 33), (2, 130, 257), (17, 17, 1000)])
+def test_ragged_shapes_vs_oracle(native, variant, rows, cols, n):
+    """Non-square meshes, cell counts that are not multiples of the 64/16-cell tiles,
+    keypoint counts that are not multiples of the split."""
+    rng = np.random.default_rng(rows * 1000 + cols * 10 + n)
+    p = synth_pair(640, 480, n, 4, seed=n)
+    xs = np.linspace(0, p.final_w, cols) + 3.0
+    ys = np.linspace(0, p.final_h, rows) + 2.0
+    verts = np.stack(np.meshgrid(xs, ys), axis=-1) + rng.normal(0, 1, (rows, cols, 2))
+    H, _ = native.local_homography(p.src, p.dst, verts, 0.5, 30.0, want_weights=False)
+    H_ref, _ = O.local_homography_loop(p.src, p.dst, verts, 0.5, 30.0, want_weights=False)
+    d = report(f"{rows}x{cols} n={n}", H, H_ref, p.src)
+    if n >= 5:
+        assert d.max() < RMSE_BAR
+    else:
+        # n = 4: the 8 x 9 system has an exact null vector, the smallest singular value is
+        # ~0 for every weight; both solvers must agree on the homography all the same
+        assert d.max() < 1e-3
+
+
+def test_all_weights_clamped(native, variant):
+    """sigma so small that every weight is gamma: all cells get the same (global DLT)
+    homography."""
+    p = synth_pair(640, 480, 200, 6, seed=5)
+    H, W = native.local_homography(p.src, p.dst, p.vertices, 0.5, 0.5)
+    assert (W == 0.5).all()
+    H_ref, _ = O.local_homography_loop(p.src, p.dst, p.vertices, 0.5, 0.5, want_weights=False)
+    assert O.reprojection_rmse_delta(H, H_ref, p.src).max() < RMSE_BAR
+    assert O.reprojection_rmse_delta(H, np.broadcast_to(H[0, 0], H.shape), p.src).max() < 1e-9
+
+
+def test_python_surface_matches_reference_signature(native, golden):
+    g = golden("tiny_sigma100")
+    fw, fh, ox, oy = (int(v) for v in g["final"])
+    eng = APAP(float(g["gamma"]), float(g["sigma"]), [fw, fh], [ox, oy])
+    H, W = eng.local_homography(g["src"], g["dst"], g["vertices"])
+    assert H.shape == (5, 5, 3, 3) and W.shape == (5, 5, 120) and W.dtype == np.float64
+    assert O.reprojection_rmse_delta(H, g["H_ref"], g["src"]).max() < RMSE_BAR
+    Harg = g["H_ref"].copy()
+    warped = eng.local_warp(g["img"], Harg, g["mesh"], False)
+    assert np.array_equal(warped, g["warped_ref"])
+    assert np.array_equal(Harg, g["Hinv_ref"])       # argument mutated like apap.py:201-203
+
+
+def test_device_entry_points_with_torch_memory(native, golden):
+    """The resident-data entry points on torch-allocated HBM give the same bits as the
+    host-buffer entry point."""
+    import ctypes
+    import torch
+    g = golden("c1_ref")
+    p = config_pair("C1", with_image=False)
+    q = native.host_prepare(p.src, p.dst)
+    table = native.host_build_table(p.src, q["cf1"], q["cf2"])
+    den = native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
+    dev = torch.device("cuda:0")
+    cells = p.vertices.shape[0] * p.vertices.shape[1]
+    d_table = torch.from_numpy(table).to(dev)
+    d_vert = torch.from_numpy(p.vertices.reshape(-1, 2).copy()).to(dev)
+    d_den = torch.from_numpy(den).to(dev)
+    d_H = torch.empty((cells, 9), dtype=torch.float32, device=dev)
+    nbytes = native.lib().apap_solve_workspace_bytes(len(p.src), cells)
+    d_work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    native.check(native.lib().apap_solve_device(d_table.data_ptr(), len(p.src), d_vert.data_ptr(), cells, p.gamma,
+                                                p.sigma, d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(),
+                                                nbytes, ctypes.c_void_p(stream)))
+    torch.cuda.synchronize()
+    H_dev = d_H.cpu().numpy().reshape(20, 20, 3, 3)
+    H_host, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    assert np.array_equal(H_dev, H_host)
+    assert O.reprojection_rmse_delta(H_dev, g["H_ref"], p.src).max() < RMSE_BAR
+    # too-small workspace is refused, not overrun
+    rc = native.lib().apap_solve_device(d_table.data_ptr(), len(p.src), d_vert.data_ptr(), cells, p.gamma, p.sigma,
+                                        d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(), 16, ctypes.c_void_p(stream))
+    assert rc == native.ERR_WORKSPACE
+
+
+def test_solve_is_bitwise_reproducible(native, variant):
+    p = config_pair("C2", with_image=False)
+    a, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    b, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ hot loop 2
+@pytest.mark.parametrize("name", TINY)
+def test_tiny_warp_vs_reference(native, golden, name):
+    g = golden(name)
+    fw, fh, ox, oy = (int(v) for v in g["final"])
+    warped, hinv = native.local_warp(g["img"], g["H_ref"], g["mesh"][0], g["mesh"][1], fw, fh, ox, oy)
+    assert np.array_equal(hinv, g["Hinv_ref"])
+    assert np.array_equal(warped, g["warped_ref"])
+
+
+def check_warp(native, img, H, mesh, fw, fh, ox, oy, ref_rows=None, every=1):
+    """Coordinates within 1 float32 ULP of the oracle's, pixels equal except where the
+    oracle coordinate is within that distance of an integer / of the image border."""
+    hinv_ref = O.invert_cells_f32(H) if H.shape[0] * H.shape[1] <= 4096 else np.linalg.inv(H.astype(np.float64)).astype(np.float32)
+    warped, hinv = native.local_warp(img, H, mesh[0], mesh[1], fw, fh, ox, oy)
+    assert ulp_diff_f32(hinv, hinv_ref).max() <= 1
+    coords = native.warp_coords(H, mesh[0], mesh[1], fw, fh, ox, oy)
+    tx, ty = O.warp_coords_fast(hinv, mesh, (fw, fh), (ox, oy))
+    ok = np.isfinite(tx) & np.isfinite(ty)
+    for got, ref in ((coords[..., 0], tx), (coords[..., 1], ty)):
+        err = np.abs(got[ok] - ref[ok])
+        assert (err <= np.spacing(np.abs(ref[ok]).astype(np.float32)).astype(np.float64)).all()
+        print(f"coordinate max abs err {err.max():.3e}")
+    ref = O.local_warp_fast(img, hinv, mesh, (fw, fh), (ox, oy))
+    diff = (warped != ref).any(axis=-1)
+    print(f"warp {fw}x{fh}: {int(diff.sum())} of {diff.size} pixels differ")
+    if diff.any():
+        # every differing pixel must be explained by a coordinate on an integer boundary
+        fx = np.abs(tx[diff] - np.round(tx[diff]))
+        fy = np.abs(ty[diff] - np.round(ty[diff]))
+        assert (np.minimum(fx, fy) < 1e-9).all()
+        assert diff.mean() < 1e-5
+    if ref_rows is not None:
+        assert np.array_equal(warped[::every], ref_rows)
+    return warped
+
+
+def test_c1_warp_vs_reference(native, golden):
+    g = golden("c1_ref")
+    p = config_pair("C1")
+    w = check_warp(native, p.img, g["H_ref"], p.mesh, p.final_w, p.final_h, p.off_x, p.off_y,
+                   ref_rows=g["warped_rows"], every=int(g["warp_rows_every"]))
+    import hashlib
+    assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
+
+
+@pytest.mark.parametrize("cfg,name", [("C2", "c2_ref"), ("C3", "c3_ref")])
+def test_full_size_warp_vs_oracle(native, golden, cfg, name):
+    p = config_pair(cfg)
+    check_warp(native, p.img, golden(name)["H_ref"], p.mesh, p.final_w, p.final_h, p.off_x, p.off_y)
+
+
+def test_identity_warp_property(native):
+    """All-identity cells, zero offsets: the canvas is the image, except row 0 and
+    column 0, which the strict `0 < t` test of apap.py:214 leaves black."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(1, 256, (333, 517, 3), dtype=np.uint8)       # 517*333 is odd: exercises the tail
+    H = np.tile(np.eye(3, dtype=np.float32), (7, 5, 1, 1))
+    mesh_w, mesh_h = np.linspace(0, 517, 6), np.linspace(0, 333, 8)
+    out, hinv = native.local_warp(img, H, mesh_w, mesh_h, 517, 333, 0, 0)
+    assert np.array_equal(hinv, H)
+    assert not out[0].any() and not out[:, 0].any()
+    assert np.array_equal(out[1:, 1:], img[1:, 1:])
+
+
+def test_translation_warp_and_offsets(native):
+    rng = np.random.default_rng(2)
+    img = rng.integers(1, 256, (64, 96, 3), dtype=np.uint8)
+    H = np.tile(np.array([[1, 0, 10], [0, 1, 5], [0, 0, 1]], np.float32), (3, 4, 1, 1))    # src -> canvas shift
+    fw, fh, ox, oy = 140, 100, 7, 9
+    mesh = O.get_mesh((fw, fh), 5)
+    mesh_w, mesh_h = np.linspace(0, fw, 5), np.linspace(0, fh, 4)
+    out, _ = native.local_warp(img, H, mesh_w, mesh_h, fw, fh, ox, oy)
+    hinv = O.invert_cells_f32(H)
+    ref = O.local_warp_fast(img, hinv, (mesh_w, mesh_h), (fw, fh), (ox, oy))
+    assert np.array_equal(out, ref) and out.any()
+
+
+def test_mesh_not_covering_canvas_is_index_error(native):
+    img = np.zeros((16, 16, 3), np.uint8)
+    H = np.tile(np.eye(3, dtype=np.float32), (2, 2, 1, 1))
+    with pytest.raises(native.ApapError) as e:
+        native.local_warp(img, H, [0.0, 8.0, 16.0], [0.0, 5.0, 10.0], 16, 16, 0, 0)   # rows 10..15 uncovered
+    assert e.value.code == native.ERR_INDEX
+    # first edge above 0: the reference indexes cell -1, i.e. the last one - allowed
+    out, _ = native.local_warp(np.full((16, 16, 3), 9, np.uint8), H, [4.0, 8.0, 16.0], [3.0, 8.0, 16.0], 16, 16, 0, 0)
+    ref = O.local_warp_fast(np.full((16, 16, 3), 9, np.uint8), H, (np.array([4.0, 8.0, 16.0]), np.array([3.0, 8.0, 16.0])), (16, 16), (0, 0))
+    assert np.array_equal(out, ref)
+
+
+def test_singular_cell_is_linalg_error(native):
+    img = np.zeros((8, 8, 3), np.uint8)
+    H = np.tile(np.eye(3, dtype=np.float32), (2, 2, 1, 1))
+    H[1, 0] = 0
+    with pytest.raises(native.ApapError) as e:
+        native.local_warp(img, H, [0.0, 4.0, 8.0], [0.0, 4.0, 8.0], 8, 8, 0, 0)
+    assert e.value.code == native.ERR_SINGULAR
+    with pytest.raises(native.ApapError) as e:
+        native.invert_normalize_flatten(H)
+    assert e.value.code == native.ERR_SINGULAR
+
+
+# ------------------------------------------------------------------ output stage, blend
+@pytest.mark.parametrize("name", ["tiny_sigma100", "c1_ref", "c2_ref"])
+def test_flatten_vs_oracle(native, golden, name):
+    H = golden(name)["H_ref"]
+    out = native.invert_normalize_flatten(H)
+    ref = O.invert_normalize_flatten(H)
+    assert out.shape == ref.shape and out.dtype == np.float64
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_blend_vs_reference(native, golden, name):
+    g = golden(name)
+    assert np.array_equal(native.uniform_blend(g["warped_ref"], g["blend_other"]), g["blended_ref"])
+
+
+def test_cli_writes_reference_mat_layout(native, tmp_path):
+    import scipy.io
+    from cvx_proj_amd.apap import main
+    assert main(["1", "1", "--synth", "C1", "--out-prefix", str(tmp_path) + "/"]) == 0
+    m = scipy.io.loadmat(str(tmp_path / "case1" / "H31_apap.mat"))["H"]
+    assert m.shape == (400, 9) and m.dtype == np.float64
+    assert np.allclose(m[:, 8], 1.0)
+    p = config_pair("C1", with_image=False)
+    H_ref, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
+    assert np.allclose(m, O.invert_normalize_flatten(H_ref), rtol=1e-5, atol=1e-7)

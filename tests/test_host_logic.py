@@ -1,0 +1,107 @@
+"""Host-side logic (no GPU): the C set-up code against the oracle bit for bit, the
+Python mirror's helpers against the reference's golden vectors, geometry, synthetic
+inputs, config reader."""
+import numpy as np
+import pytest
+
+from oracle import apap_oracle as O
+from cvx_proj_amd import geometry, synth
+from cvx_proj_amd.apap import APAP, read_config
+
+MOMENT_INDEX = ([(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+                + [(i, 6 + j) for i in range(3) for j in range(3)]
+                + [(3 + i, 6 + j) for i in range(3) for j in range(3)]
+                + [(6, 6), (6, 7), (6, 8), (7, 7), (7, 8), (8, 8)])
+
+
+@pytest.mark.parametrize("name", ["tiny_sigma100", "tiny_sigma6"])
+def test_c_prepare_matches_reference_vectors(native, golden, name):
+    g = golden(name)
+    q = native.host_prepare(g["src"], g["dst"])
+    for k in ("N1", "N2", "C1", "C2", "nf1", "nf2", "cf1", "cf2"):
+        assert np.array_equal(q[k], g[k]), k
+    assert np.array_equal(native.host_dlt_rows(q["cf1"], q["cf2"]), g["aa"])
+    assert np.array_equal(q["iC2"], np.linalg.inv(g["C2"]))
+    assert np.array_equal(q["iN2"], np.linalg.inv(g["N2"]))
+
+
+def test_c_prepare_matches_oracle_random(native):
+    rng = np.random.default_rng(3)
+    sizes = [2, 3, 7, 8, 9, 127, 128, 129, 1000, 2000, 5000] + [int(v) for v in rng.integers(10, 6000, 40)]
+    for t, n in enumerate(sizes):
+        w, h = rng.choice([200, 1920, 3840, 7680]), rng.choice([140, 1080, 2160, 4320])
+        src = (rng.random((n, 2)) * [w, h]).astype(np.float32)
+        dst = (src + rng.normal(0, 5, (n, 2)) + [30, -20]).astype(np.float32)
+        if t == 5:
+            src[:, 0] = 5.0            # zero spread along x: the std == 0 guard of apap.py:81-82
+        p = O.prepare(src, dst)
+        q = native.host_prepare(src, dst)
+        for k in ("N1", "N2", "C1", "C2", "iC2", "iN2", "nf1", "nf2", "cf1", "cf2"):
+            assert np.array_equal(p[k], q[k]), (n, k)
+        aa = native.host_dlt_rows(q["cf1"], q["cf2"])
+        assert np.array_equal(aa, p["aa"])
+        table = native.host_build_table(src, q["cf1"], q["cf2"])
+        P = O.moments_from_rows(aa)
+        assert np.array_equal(table[:, :30], np.stack([P[:, i, j] for i, j in MOMENT_INDEX], axis=1))
+        assert np.array_equal(table[:, 30:], src.astype(np.float64))
+        # the block structure the kernels rely on
+        assert np.array_equal(P[:, 3:6, 3:6], P[:, 0:3, 0:3]) and not P[:, 0:3, 3:6].any()
+        den = native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
+        assert np.array_equal(den, np.concatenate([q[k].astype(np.float64).ravel() for k in ("iC2", "C1", "iN2", "N1")]))
+
+
+def test_singular_normaliser_is_reported(native):
+    # all keypoints identical: mean distance 0 -> scale = sqrt(2)/1e-8, still invertible;
+    # a NaN keypoint makes the pivots NaN, not zero - numpy raises nothing either.
+    src = np.full((4, 2), 3.0, np.float32)
+    q = native.host_prepare(src, src)
+    assert np.isfinite(q["N1"]).all() and q["C1"][0, 0] == np.float32(np.sqrt(2))
+
+
+@pytest.mark.parametrize("name", ["tiny_sigma100", "tiny_sigma6"])
+def test_python_mirror_helpers(native, golden, name):
+    g = golden(name)
+    N1, nf1 = APAP.getNormalize2DPts(g["src"])
+    N2, nf2 = APAP.getNormalize2DPts(g["dst"])
+    assert np.array_equal(N1, g["N1"]) and np.array_equal(nf1, g["nf1"])
+    assert np.array_equal(N2, g["N2"]) and np.array_equal(nf2, g["nf2"])
+    C1 = APAP.getConditionerFromPts(nf1)
+    C2 = APAP.getConditionerFromPts(nf2)
+    assert np.array_equal(C1, g["C1"]) and np.array_equal(C2, g["C2"])
+    cf1 = APAP.point_normalize(nf1, C1)
+    cf2 = APAP.point_normalize(nf2, C2)
+    assert np.array_equal(cf1, g["cf1"]) and np.array_equal(cf2, g["cf2"])
+    assert np.array_equal(APAP.matrix_generate(len(cf1), cf1, cf2), g["aa"])
+    t = APAP.warp_coordinate_estimate(np.array([3, 4, 1]), g["Hinv_ref"][0, 0])
+    assert t.dtype == np.float64 and t[2] == 1.0
+
+
+@pytest.mark.parametrize("name", ["tiny_sigma100", "tiny_sigma6"])
+def test_geometry_matches_reference(golden, name):
+    g = golden(name)
+    fw, fh, ox, oy = (int(v) for v in g["final"])
+
+    class S:
+        shape = g["img"].shape
+
+    assert tuple(int(v) for v in geometry.final_size(S, S, g["Hg"])) == (fw, fh, ox, oy)
+    assert np.array_equal(geometry.get_mesh((fw, fh), 6), g["mesh"])
+    assert np.array_equal(geometry.get_vertice((fw, fh), 5, (ox, oy)), g["vertices"])
+    assert np.array_equal(geometry.uniform_blend(g["warped_ref"], g["blend_other"]), g["blended_ref"])
+
+
+def test_synth_is_deterministic_and_matches_golden_canvas(golden):
+    a = synth.config_pair("C2", with_image=False)
+    b = synth.config_pair("C2", with_image=False)
+    assert np.array_equal(a.src, b.src) and np.array_equal(a.dst, b.dst)
+    assert (a.final_w, a.final_h, a.off_x, a.off_y) == tuple(int(v) for v in golden("c2_ref")["final"])
+    assert a.vertices.shape == (100, 100, 2) and a.mesh.shape == (2, 101)
+    c = synth.config_pair("C1", with_image=True)
+    assert c.img.shape == (768, 768, 3) and c.img.dtype == np.uint8
+
+
+def test_config_reader(tmp_path):
+    f = tmp_path / "case1.txt"
+    f.write_text("em_steps = 2\naffinity_eps = 30.0\nmesh_size = 40\nsigma = 12.5  # comment\n")
+    cfg = read_config(str(f))
+    assert cfg["mesh_size"] == "40" and float(cfg["sigma"]) == 12.5 and cfg["em_steps"] == "2"
