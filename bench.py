@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Benchmark of the APAP hot path on MI355X: local homographies/s and warp Mpix/s on the
+4K pair / 200x200 mesh / 2000 keypoints configuration of BASELINE.json (C3).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--variant auto|valu|mfma]
+                    [--no-cpu-baseline] [--mode pairs|cells]
+
+A "step" is one pass of the hot path over one image pair with all inputs resident in
+HBM: the per-cell solve (assemble + eigen-solve kernels) and the backward warp
+(invert + lookup + gather kernels).  The two halves of the metric are timed in two
+regions of exactly K steps each, both bracketed by a barrier and a device synchronise:
+``value`` = cells * K * N / t_solve (homographies/s), ``warp.value`` = canvas pixels
+* K * N / t_warp (Mpix/s), ``ms_per_step`` = (t_solve + t_warp) / K.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ``--mode pairs``
+(default) gives every rank its own 4K pair - pairs are independent, no collective on
+the data path, weak scaling.  ``--mode cells`` shards the mesh rows of ONE pair over
+the ranks with a broadcast of the keypoint table and an all-gather of the H grid
+(cvx_proj_amd.dist), strong scaling.
+
+Extra objects on the JSON line: ``roofline`` for the dominant kernel (K1, timed live
+with HIP events on the launch stream) and ``cpu_baseline`` (the oracle's
+faithful-loop numpy port timed on this host, one thread, bounded sample).
+"""
+import os
+
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # the CPU baseline is the 1-thread port
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import argparse
+import ctypes
+import json
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cvx_proj_amd import _native as N  # noqa: E402
+from cvx_proj_amd.synth import CONFIGS, config_pair  # noqa: E402
+
+METRIC = "local homographies/sec + Mpix/sec warp, 4K pair 200x200 mesh"
+# Peaks (DESIGN.md section "Rooflines"): fp64 matrix = fp64 vector = 78.6 TFLOP/s is AMD's
+# MI355X datasheet figure (256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk); HBM 8 TB/s spec from
+# /opt/skills/guides/MI355X_MICROARCH.md.
+PEAK_FP64_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+# algorithmic flops per (cell, keypoint) of K1, SURVEY.md 8(d): 8 (weight) + 48 (24 FMAs) + 2
+K1_FLOPS_PER_CELL_POINT = 58.0
+
+
+class Resident:
+    """One image pair with everything the hot path reads resident in HBM."""
+
+    def __init__(self, pair, dev):
+        self.pair = pair
+        q = N.host_prepare(pair.src, pair.dst)
+        table = N.host_build_table(pair.src, q["cf1"], q["cf2"])
+        den = N.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
+        self.n = len(pair.src)
+        self.rows, self.cols = pair.vertices.shape[:2]
+        self.cells = self.rows * self.cols
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.table, self.den = t(table), t(den)
+        self.vert = t(pair.vertices.reshape(-1, 2))
+        self.H = torch.zeros((self.cells, 9), dtype=torch.float32, device=dev)
+        self.work_bytes = max(N.lib().apap_solve_workspace_bytes(self.n, self.cells), 256)
+        self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=dev)
+        self.img = t(pair.img)
+        self.mesh_w, self.mesh_h = t(pair.mesh[0]), t(pair.mesh[1])
+        self.out = torch.zeros((pair.final_h, pair.final_w, 3), dtype=torch.uint8, device=dev)
+        self.wwork_bytes = N.lib().apap_warp_workspace_bytes(self.rows, self.cols, pair.final_w, pair.final_h)
+        self.wwork = torch.empty(self.wwork_bytes, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def solve(self, stream):
+        p = self.pair
+        N.check(N.lib().apap_solve_device(self.table.data_ptr(), self.n, self.vert.data_ptr(), self.cells,
+                                          p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(),
+                                          self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
+
+    def warp(self, stream):
+        p = self.pair
+        N.check(N.lib().apap_warp_device(self.img.data_ptr(), p.shape[0], p.shape[1], self.H.data_ptr(), self.rows,
+                                         self.cols, self.mesh_w.data_ptr(), p.mesh.shape[1], self.mesh_h.data_ptr(),
+                                         p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
+                                         self.out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
+                                         self.status.data_ptr(), ctypes.c_void_p(stream)))
+
+
+def cpu_baseline(cfg, budget_cells, budget_rows):
+    """The oracle's faithful-loop port on this host: a bounded, seeded sample of the
+    same workload (cells spread over the mesh; every k-th canvas row)."""
+    from oracle import apap_oracle as O
+    p = config_pair(cfg)
+    rows, cols = p.vertices.shape[:2]
+    rng = np.random.default_rng(0)
+    flat = rng.choice(rows * cols, size=min(budget_cells, rows * cols), replace=False)
+    cells = [(int(f // cols), int(f % cols)) for f in flat]
+    t0 = time.perf_counter()
+    H, _ = O.local_homography_loop(p.src, p.dst, p.vertices, p.gamma, p.sigma, cells=cells, want_weights=True)
+    t_solve = time.perf_counter() - t0
+    H_full, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
+    sub = list(range(0, p.final_h, max(1, p.final_h // budget_rows)))[:budget_rows]
+    hinv = H_full.copy()
+    t0 = time.perf_counter()
+    O.local_warp_loop(p.img, hinv, p.mesh, (p.final_w, p.final_h), (p.off_x, p.off_y), rows_subset=sub)
+    t_warp = time.perf_counter() - t0
+    # the in-place inversion of all cells is part of local_warp; it is inside t_warp, as in the reference
+    return {
+        "value": len(cells) / t_solve, "unit": "homographies/s", "cores": 1, "kind": "port",
+        "sample": f"{len(cells)} of {rows * cols} cells (seeded random), {len(sub)} of {p.final_h} canvas rows + all "
+                  f"{rows * cols} cell inversions; oracle faithful-loop numpy port, OPENBLAS_NUM_THREADS=1, "
+                  f"host has {os.cpu_count()} logical cores",
+        "warp_value": len(sub) * p.final_w / t_warp / 1e6, "warp_unit": "Mpix/s",
+        "solve_s": t_solve, "warp_s": t_warp,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
+    ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "cells"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cells", type=int, default=6000)
+    ap.add_argument("--cpu-rows", type=int, default=96)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist = None
+
+    N.lib().apap_set_solver_variant({"auto": 0, "valu": 1, "mfma": 2}[a.variant])
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.mode == "cells" and world > 1:
+        from cvx_proj_amd.dist import ShardedSolver
+        pair = config_pair(a.config)
+        res = ShardedSolver(pair, dev, dist)
+        units_solve = res.cells_total                # strong scaling: one pair for the whole job
+        units_warp = pair.final_w * pair.final_h
+        scaling = "strong"
+    else:
+        pair = config_pair(a.config, seed_offset=rank)
+        res = Resident(pair, dev)
+        units_solve = res.cells * world
+        units_warp = pair.final_w * pair.final_h * world
+        scaling = "weak"
+
+    for _ in range(a.warmup):
+        res.solve(stream)
+        res.warp(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res.solve(stream)
+    barrier()
+    t_solve = time.perf_counter() - t0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res.warp(stream)
+    barrier()
+    t_warp = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([t_solve, t_warp], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_solve, t_warp = (float(v) for v in tt.cpu())
+    assert int(res.status.cpu()[0]) == 0, "device status word set during the timed region"
+
+    # per-kernel durations, HIP events on the launch stream (rank-local)
+    N.lib().apap_profile_enable(1)
+    for _ in range(a.steps):
+        res.solve(stream)
+        res.warp(stream)
+    torch.cuda.synchronize()
+    ms = (ctypes.c_float * 5)()
+    cnt = (ctypes.c_int * 5)()
+    N.check(N.lib().apap_profile_read(ms, cnt))
+    N.lib().apap_profile_enable(0)
+    kern = {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(["assemble", "eigen", "invert", "lut", "warp"])}
+
+    if rank == 0:
+        local_cells = res.cells
+        flops = K1_FLOPS_PER_CELL_POINT * res.n * local_cells
+        t_k1 = kern["assemble"] * 1e-3
+        achieved = flops / t_k1 / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(f"{a.config}:{a.variant}:assemble")
+        # K3 (HBM-bound half of the metric): 6 B per in-range pixel, 3 B per blank one
+        out_pixels = pair.final_w * pair.final_h
+        nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu()) if a.mode == "pairs" or world == 1 else None
+        warp_bytes = (6 * nz + 3 * (out_pixels - nz)) if nz is not None else None
+        line = {
+            "metric": METRIC, "value": units_solve * a.steps / t_solve, "unit": "homographies/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": (t_solve + t_warp) / a.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {CONFIGS[a.config][0]}x{CONFIGS[a.config][1]} pair, "
+                                   f"{res.n} correspondences, {res.rows}x{res.cols} mesh, canvas "
+                                   f"{pair.final_w}x{pair.final_h}", "mode": a.mode, "variant": a.variant,
+                       "parallelism": f"{a.mode}x{world}"},
+            "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
+                     "ms_per_step": t_warp / a.steps * 1e3},
+            "solve_ms_per_step": t_solve / a.steps * 1e3,
+            "kernels_ms": kern,
+            "roofline": {"kernel": "k_assemble_" + ("mfma" if a.variant == "mfma" else "valu"), "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "note": "fp64 FMA work: peak is the fp64 matrix = fp64 vector rate; algorithmic "
+                                 "58 flop per (cell, keypoint)"},
+            "roofline_warp": None if warp_bytes is None else {
+                "kernel": "k_warp", "bound": "hbm", "achieved": warp_bytes / (kern["warp"] * 1e-3) / 1e9,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (kern["warp"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": None},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

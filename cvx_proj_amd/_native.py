@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -42,6 +43,8 @@ SIGNATURES = {
     "apap_version": (C.c_char_p, []),
     "apap_device_count": (C.c_int, []),
     "apap_set_solver_variant": (C.c_int, [C.c_int]),
+    "apap_profile_enable": (C.c_int, [C.c_int]),
+    "apap_profile_read": (C.c_int, [_f32p, _i32p]),
     "apap_host_prepare": (C.c_int, [_f32p, _f32p, C.c_int] + [_f32p] * 10),
     "apap_host_dlt_rows": (C.c_int, [_f32p, _f32p, C.c_int, _f32p]),
     "apap_host_build_table": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, _f64p]),
@@ -77,6 +80,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ApapError(ERR_NO_DEVICE, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; "
                                            "g.build()'` or `make -C cvx_proj_amd/csrc`")
+        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (same
+        # SONAME as /opt/rocm's, different file); if this library pulled in /opt/rocm's
+        # copy first, a later `import torch` would load a second runtime that sees no
+        # GPU.  Importing torch first makes both share torch's copy; without torch (or
+        # with APAP_HIP_STANDALONE=1) the RPATH to /opt/rocm/lib is used.
+        if "torch" not in sys.modules and os.environ.get("APAP_HIP_STANDALONE", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -19,7 +19,7 @@ struct SolvePlan {
     int cells_pad;     // cells rounded up to the cell tile of the variant
     int cell_tiles;    // grid.x
     int splits;        // grid.y: independent slices of the keypoint list
-    int pts_per_wave;  // keypoints each wave walks (VALU) / per block slice (MFMA)
+    int pts_per_split; // keypoints per slice (a multiple of 4)
     size_t moment_bytes;
 };
 SolvePlan plan_solve(int n, int cells, int variant);

@@ -14,6 +14,8 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is written fma().
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "apap_internal.h"
 
 namespace {
@@ -43,7 +45,7 @@ __device__ __forceinline__ double cell_weight(double vx, double vy, double sx, d
 __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
                                                        int cells_pad, double gamma, double inv_sigma,
-                                                       int pts_per_wave, double *__restrict__ moments) {
+                                                       int pts_per_split, double *__restrict__ moments) {
     __shared__ double red[3][kMoments][kWave];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -51,9 +53,10 @@ __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict_
     const int cc = min(cell, cells - 1);
     const double vx = vertices[2 * cc];
     const double vy = vertices[2 * cc + 1];
-    const int slice = blockIdx.y * 4 + wave;
-    const int p0 = min(n, slice * pts_per_wave);
-    const int p1 = min(n, p0 + pts_per_wave);
+    const int pts_per_wave = pts_per_split / 4;  // pts_per_split is a multiple of 4
+    const int split_end = min(n, (int)(blockIdx.y + 1) * pts_per_split);
+    const int p0 = min(split_end, (int)blockIdx.y * pts_per_split + wave * pts_per_wave);
+    const int p1 = min(split_end, p0 + pts_per_wave);
 
     double acc[kMoments];
 #pragma unroll
@@ -82,6 +85,101 @@ __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict_
             s += red[2][j][lane];
             dst[(size_t)j * cells_pad] = s;
         }
+    }
+}
+
+// --------------------------------------------------------------------------------
+// K1 (MFMA variant): the 30 moment sums of 16 cells over 4 keypoints are one
+// v_mfma_f64_16x16x4_f64:  D[cell][moment] += A[cell][point] * B[point][moment] with
+// A = w^2 (computed by the lane that owns (cell = lane & 15, point = lane >> 4)) and
+// B = the keypoint table staged in LDS.  Two MFMAs cover the 32 table columns (30
+// moments + the keypoint's x, y, whose sums are ignored).  The matrix pipe does the
+// accumulation and the cross-keypoint reduction; the vector unit only computes weights.
+// A block is 4 waves = 64 cells sharing each 64-keypoint LDS chunk (16 KiB, double
+// buffered, register-staged so the next chunk's global loads fly during the MFMAs).
+// --------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+constexpr int kChunk = 64;  // keypoints per LDS buffer
+
+// Byte offset of table entry (row r, column c) in an LDS chunk: 256-B rows; odd rows swap
+// their 128-B halves so that the two keypoint rows a 32-lane ds_read_b64 covers (lanes
+// 0-15 -> row r, 16-31 -> row r+1) fall on disjoint halves of the 64 banks.
+__device__ __forceinline__ int lds_off(int r, int c) { return r * 256 + ((c ^ ((r & 1) << 4)) << 3); }
+
+__global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict__ table, int n,
+                                                       const double *__restrict__ vertices, int cells,
+                                                       int cells_pad, double gamma, double inv_sigma,
+                                                       int pts_per_split, double *__restrict__ moments) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kgrp = lane >> 4;  // which of the step's 4 keypoints this lane weighs
+    const int col = lane & 15;   // cell within the wave's 16 (A operand) / table column (B operand)
+    const int cell = blockIdx.x * 64 + wave * 16 + col;
+    const int cc = min(cell, cells - 1);
+    const double vx = vertices[2 * cc];
+    const double vy = vertices[2 * cc + 1];
+    const int p_begin = min(n, (int)blockIdx.y * pts_per_split);
+    const int p_end = min(n, p_begin + pts_per_split);
+    const int nchunks = (p_end - p_begin + kChunk - 1) / kChunk;
+
+    // staging: thread t moves 16-byte pieces t, t+256, t+512, t+768 of a chunk;
+    // piece q = (row q >> 4, 16-byte slot q & 15)
+    double2 stage[4];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            const int p = p_begin + c * kChunk + (q >> 4);
+            stage[i] = (p < p_end) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
+                                   : make_double2(0.0, 0.0);  // zero rows add nothing whatever their weight
+        }
+    };
+    auto store_chunk = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + 256 * i;
+            const int r = q >> 4;
+            const int slot = (q & 15) ^ ((r & 1) << 3);
+            *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[i];
+        }
+    };
+
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const unsigned char *buf = lds[c & 1];
+        // a partial last chunk runs all 16 steps: its missing rows are zero
+#pragma unroll 4
+        for (int s = 0; s < kChunk / 4; ++s) {
+            const int r = 4 * s + kgrp;
+            const double2 xy = *reinterpret_cast<const double2 *>(buf + lds_off(r, 30));
+            const double b0 = *reinterpret_cast<const double *>(buf + lds_off(r, col));
+            const double b1 = *reinterpret_cast<const double *>(buf + lds_off(r, 16 + col));
+            const double w = cell_weight(vx, vy, xy.x, xy.y, inv_sigma, gamma);
+            const double w2 = w * w;
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // D layout of v_mfma_f64_16x16x4_f64: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15],
+    // row = cell within the wave's 16, col = moment index (acc0: 0..15, acc1: 16..31).
+    double *slab = moments + (size_t)blockIdx.y * kMoments * cells_pad;
+    const int cell_base = blockIdx.x * 64 + wave * 16 + kgrp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = cell_base + 4 * i;
+        slab[(size_t)col * cells_pad + ci] = acc0[i];
+        if (col < kMoments - 16) slab[(size_t)(16 + col) * cells_pad + ci] = acc1[i];
     }
 }
 
@@ -151,7 +249,7 @@ constexpr int kMaxSweeps = 15;
 
 __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
                                                      int cells, int cells_pad,
-                                                     const double *__restrict__ denorm,
+                                                     const double *__restrict__ denorm, int pick_rank,
                                                      float *__restrict__ H) {
     const int cell = blockIdx.x * kWave + threadIdx.x;
     const int cc = min(cell, cells - 1);
@@ -199,14 +297,24 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
         if (__all(done)) break;
     }
 
-    // smallest eigenvalue -> column of V (numpy/OpenCV sort singular values descending
-    // and the reference takes the last row of V^T, apap.py:160-161)
+    // Which eigenvector: the reference takes the LAST row of the V^T that the thin SVD
+    // of the 2n x 9 system returns, singular values sorted descending (apap.py:160-161).
+    // For 2n >= 9 that is the smallest eigenvalue of A^T W^2 A (pick_rank 0); for fewer
+    // rows the thin V^T has only 2n rows and the last one belongs to the
+    // (9 - 2n)-th smallest eigenvalue.  Rank = number of strictly smaller diagonal
+    // entries, ties broken by index.
     int best = 0;
-    double bestv = a[tri(0, 0)];
 #pragma unroll
-    for (int i = 1; i < 9; ++i) {
-        const double d = a[tri(i, i)];
-        if (d < bestv) { bestv = d; best = i; }
+    for (int i = 0; i < 9; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j != i) {
+                const double di = a[tri(i, i)], dj = a[tri(j, j)];
+                rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+            }
+        }
+        best = (rank == pick_rank) ? i : best;
     }
     double h[9];
 #pragma unroll
@@ -485,6 +593,31 @@ inline int hip_fail(hipError_t e, const char *what) {
 
 int g_variant = APAP_VARIANT_AUTO;
 
+// ---- optional per-kernel timing with HIP events on the launch stream ----
+struct ProfSpan {
+    int slot;
+    hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::vector<ProfSpan> g_prof;
+
+struct ProfScope {
+    hipStream_t s;
+    ProfSpan span;
+    bool on;
+    ProfScope(int slot, hipStream_t stream) : s(stream), on(g_prof_on) {
+        if (!on) return;
+        span.slot = slot;
+        on = hipEventCreate(&span.a) == hipSuccess && hipEventCreate(&span.b) == hipSuccess;
+        if (on) (void)hipEventRecord(span.a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(span.b, s);
+        g_prof.push_back(span);
+    }
+};
+
 }  // namespace
 
 namespace apap {
@@ -493,17 +626,19 @@ SolvePlan plan_solve(int n, int cells, int variant) {
     SolvePlan p{};
     if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_VALU;
     p.variant = variant;
-    p.cell_tiles = (cells + kWave - 1) / kWave;
+    p.cell_tiles = (cells + kWave - 1) / kWave;  // both variants: 64 cells per 4-wave block
     p.cells_pad = p.cell_tiles * kWave;
-    // Fill the chip: 256 CUs x 4 SIMDs; aim at >= 2 waves per SIMD.  A block already
-    // splits the keypoints 4 ways; add grid-level splits for small meshes, but keep
-    // at least 64 keypoints per wave.
+    // Fill the chip (256 CUs x 4 SIMDs): aim at >= 2 waves per SIMD.  Small meshes split
+    // the keypoint list over grid.y; each split writes its own moment slab and K2 adds
+    // the slabs in a fixed order.  Keep >= 256 keypoints per split.
     int splits = 1;
     const int want_waves = 2048;
-    while (splits < 16 && p.cell_tiles * 4 * splits < want_waves && n / (4 * splits * 2) >= 64) splits *= 2;
-    p.splits = splits;
-    p.pts_per_wave = (n + 4 * splits - 1) / (4 * splits);
-    p.moment_bytes = (size_t)splits * kMoments * p.cells_pad * sizeof(double);
+    while (splits < 16 && p.cell_tiles * 4 * splits < want_waves && n / (splits * 2) >= 256) splits *= 2;
+    int pps = (n + splits - 1) / splits;
+    pps = (pps + 3) / 4 * 4;
+    p.splits = (n + pps - 1) / pps;  // no empty split
+    p.pts_per_split = pps;
+    p.moment_bytes = (size_t)p.splits * kMoments * p.cells_pad * sizeof(double);
     return p;
 }
 
@@ -535,10 +670,21 @@ int apap_solve_device(const double *d_table, int n, const double *d_vertices, in
     hipStream_t s = (hipStream_t)stream;
     const double inv_sigma = 1.0 / (sigma * sigma);  // apap.py:142
     double *moments = (double *)d_work;
-    hipLaunchKernelGGL(k_assemble_valu, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
-                       cells, p.cells_pad, gamma, inv_sigma, p.pts_per_wave, moments);
-    hipLaunchKernelGGL(k_eigen_denorm, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
-                       p.cells_pad, d_denorm, d_H);
+    {
+    ProfScope prof(APAP_PROF_ASSEMBLE, s);
+    if (p.variant == APAP_VARIANT_MFMA)
+        hipLaunchKernelGGL(k_assemble_mfma, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
+                           cells, p.cells_pad, gamma, inv_sigma, p.pts_per_split, moments);
+    else
+        hipLaunchKernelGGL(k_assemble_valu, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
+                           cells, p.cells_pad, gamma, inv_sigma, p.pts_per_split, moments);
+    }
+    const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
+    {
+        ProfScope prof(APAP_PROF_EIGEN, s);
+        hipLaunchKernelGGL(k_eigen_denorm, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
+                           p.cells_pad, d_denorm, pick_rank, d_H);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
     return APAP_OK;
@@ -578,10 +724,16 @@ static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, cons
     const size_t hinv_bytes = (((size_t)cells * APAP_HINV_STRIDE * sizeof(float) + 255) / 256) * 256;
     *hinv_pad = (float *)d_work;
     *lut = (int *)((char *)d_work + hinv_bytes);
-    hipLaunchKernelGGL(k_invert_cells, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
-                       d_Hinv_out, d_status);
-    hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
-                       d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
+    {
+        ProfScope prof(APAP_PROF_INVERT, s);
+        hipLaunchKernelGGL(k_invert_cells, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+                           d_Hinv_out, d_status);
+    }
+    {
+        ProfScope prof(APAP_PROF_LUT, s);
+        hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
+                           d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
+    }
     return APAP_OK;
 }
 
@@ -600,8 +752,11 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
     if (rc != APAP_OK) return rc;
     const size_t total = (size_t)final_w * final_h;
     const size_t threads = (total + 3) / 4;
-    hipLaunchKernelGGL(k_warp, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_img, img_h, img_w,
-                       hinv_pad, mesh_cols, lut, final_w, final_h, off_x, off_y, d_out);
+    {
+        ProfScope prof(APAP_PROF_WARP, s);
+        hipLaunchKernelGGL(k_warp, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_img, img_h, img_w,
+                           hinv_pad, mesh_cols, lut, final_w, final_h, off_x, off_y, d_out);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
     return APAP_OK;
@@ -624,6 +779,33 @@ int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, c
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_coords_device launch");
     return APAP_OK;
+}
+
+int apap_profile_enable(int on) {
+    const int prev = g_prof_on ? 1 : 0;
+    g_prof_on = on != 0;
+    return prev;
+}
+
+int apap_profile_read(float *ms, int *launches) {
+    if (!ms || !launches) return apap::fail(APAP_ERR_INVALID_ARG, "apap_profile_read: null argument");
+    for (int k = 0; k < APAP_PROF_SLOTS; ++k) {
+        ms[k] = 0.0f;
+        launches[k] = 0;
+    }
+    int rc = APAP_OK;
+    for (ProfSpan &sp : g_prof) {
+        float t = 0.0f;
+        hipError_t e = hipEventSynchronize(sp.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, sp.a, sp.b);
+        if (e != hipSuccess) rc = hip_fail(e, "apap_profile_read");
+        ms[sp.slot] += t;
+        launches[sp.slot] += 1;
+        (void)hipEventDestroy(sp.a);
+        (void)hipEventDestroy(sp.b);
+    }
+    g_prof.clear();
+    return rc;
 }
 
 int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_status, void *stream) {

@@ -56,6 +56,14 @@ extern "C" {
 #define APAP_VARIANT_VALU 1 /* one lane per cell, fp64 FMA accumulation            */
 #define APAP_VARIANT_MFMA 2 /* v_mfma_f64_16x16x4_f64 accumulation, table via LDS  */
 
+/* Kernel slots of apap_profile_read. */
+#define APAP_PROF_ASSEMBLE 0 /* K1: weighted moment sums A^T W^2 A      */
+#define APAP_PROF_EIGEN 1    /* K2: Jacobi eigen-solve + de-normalise   */
+#define APAP_PROF_INVERT 2   /* per-cell 3x3 inverse                    */
+#define APAP_PROF_LUT 3      /* canvas row/column -> cell lookup table  */
+#define APAP_PROF_WARP 4     /* K3: backward warp gather                */
+#define APAP_PROF_SLOTS 5
+
 /* ---------------------------------------------------------------- diagnostics --- */
 const char *apap_last_error(void);
 const char *apap_version(void);
@@ -63,6 +71,13 @@ const char *apap_version(void);
 int apap_device_count(void);
 /* Select the assembly kernel; returns the previous value.  Process-wide. */
 int apap_set_solver_variant(int variant);
+
+/* Per-kernel timing.  While enabled, the "_device" entry points bracket every kernel
+ * with HIP events recorded on the launch stream.  apap_profile_read waits for them and
+ * returns, per slot, the summed milliseconds and the number of launches since the
+ * previous read.  Not thread-safe; meant for bench.py. */
+int apap_profile_enable(int on);
+int apap_profile_read(float *ms, int *launches);
 
 /* ------------------------------------------------------------ host-only helpers --- */
 /* No GPU needed.  They restate, in C and in float32 exactly as numpy evaluates the

@@ -246,7 +246,9 @@ def local_homography_fast(src_point, dst_point, vertices, gamma, sigma, chunk=40
             W[lo:lo + chunk] = w
         M = ((w * w) @ P).reshape(-1, 9, 9)
         _, vec = np.linalg.eigh(M)
-        h = vec[:, :, 0].reshape(-1, 3, 3)
+        # last row of the THIN V^T (apap.py:160-161): smallest eigenvalue when 2n >= 9,
+        # otherwise the smallest of the 2n that the thin SVD keeps
+        h = vec[:, :, 9 - min(2 * n, 9)].reshape(-1, 3, 3)
         h = iC2 @ h @ C1
         h = iN2 @ h @ N1
         h = h / h[:, 2:3, 2:3]

@@ -1,0 +1,87 @@
+// Microbenchmark: sustained fp64 rate of the vector unit (v_fma_f64) and of the matrix
+// pipe (v_mfma_f64_16x16x4_f64) on this device.  SURVEY.md 8(d) asks for the fp64 peak to
+// be confirmed on the box before it is used as a roofline denominator, because the local
+// micro-architecture guide lists no fp64 figure.
+//   hipcc --offload-arch=gfx950 -O3 tools/peak_fp64.hip -o tools/peak_fp64 && tools/peak_fp64
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+template <int ACC>
+__global__ __launch_bounds__(256) void k_fma(double *out, int iters, double a, double b) {
+    double x[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) x[i] = threadIdx.x * 1e-3 + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) x[i] = fma(x[i], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += x[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int ACC>
+__global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a, double b) {
+    double4_t acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = double4_t{0, 0, 0, 0};
+    const double av = a + threadIdx.x * 1e-6, bv = b + threadIdx.x * 1e-6;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <typename F>
+double time_ms(F launch, int reps) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < reps; ++r) launch();
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / reps;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    printf("device: %s, %d CUs, clock %d MHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+    const int blocks = prop.multiProcessorCount * 8, threads = 256, iters = 20000;
+    double *out;
+    hipMalloc(&out, sizeof(double) * blocks * threads);
+    {
+        constexpr int ACC = 8;
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_fma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.999999, 1e-9); }, 5);
+        const double flops = 2.0 * ACC * iters * (double)blocks * threads;
+        printf("v_fma_f64   (8 chains/lane, %d waves): %.3f ms  %.2f TFLOP/s\n", blocks * 4, ms, flops / ms / 1e9);
+    }
+    {
+        constexpr int ACC = 4;
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
+        const double flops = 2.0 * 16 * 16 * 4 * ACC * iters * (double)blocks * (threads / 64);
+        printf("v_mfma_f64_16x16x4_f64 (4 acc/wave, %d waves): %.3f ms  %.2f TFLOP/s\n", blocks * 4, ms, flops / ms / 1e9);
+    }
+    {
+        constexpr int ACC = 1;
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
+        const double flops = 2.0 * 16 * 16 * 4 * ACC * iters * (double)blocks * (threads / 64);
+        printf("v_mfma_f64_16x16x4_f64 (1 dependent acc/wave, 8 waves/SIMD): %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+    }
+    hipFree(out);
+    return 0;
+}
