@@ -1,0 +1,142 @@
+"""Multi-GPU driver for the APAP path: one process per GPU, ``torch.distributed``
+(backend ``nccl`` = RCCL over xGMI on ROCm; ``gloo`` in the CPU tests).
+
+The path shards in two ways:
+
+* **cells of one pair** (config C4): every mesh cell is independent given the keypoint
+  table.  Rank 0 prepares the table on its host and *broadcasts* it (n x 256 B - 1.3 MB at
+  n = 5000); each rank solves a contiguous block of mesh rows; one *all-gather* assembles
+  the H grid (36 B per cell - 5.8 MB at 400 x 400, 720 KB per rank: on fully connected xGMI
+  that is one hop and latency-bound, so it is a single un-bucketed collective).
+* **independent pairs** (config C5): pairs are dealt round-robin to the ranks; no
+  collective on the data path, one gather of the H grids at the end.
+
+The compute itself is injected (``solve_fn``) so that the partitioning and the
+collectives can be tested on CPU ranks; the default is the HIP engine and there is no
+CPU fallback in this module.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native
+
+
+def row_partition(rows, world):
+    """Contiguous, near-equal blocks of mesh rows: ``[(start, stop)] * world``.  The first
+    ``rows % world`` ranks get one row more; ranks beyond ``rows`` get empty blocks."""
+    base, extra = divmod(rows, world)
+    out, start = [], 0
+    for r in range(world):
+        size = base + (1 if r < extra else 0)
+        out.append((start, start + size))
+        start += size
+    return out
+
+
+def hip_solve(table, denorm, vertices, gamma, sigma):
+    """Default ``solve_fn``: resident-data C-ABI call on the tensors' device."""
+    if not table.is_cuda:
+        raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_solve needs CUDA/HIP tensors; there is no CPU fallback")
+    cells = vertices.shape[0]
+    n = table.shape[0]
+    H = torch.empty((cells, 9), dtype=torch.float32, device=table.device)
+    if cells == 0:
+        return H
+    nbytes = max(_native.lib().apap_solve_workspace_bytes(n, cells), 256)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+    stream = torch.cuda.current_stream(table.device).cuda_stream
+    _native.check(_native.lib().apap_solve_device(table.data_ptr(), n, vertices.data_ptr(), cells, float(gamma),
+                                                  float(sigma), denorm.data_ptr(), H.data_ptr(), work.data_ptr(),
+                                                  nbytes, ctypes.c_void_p(stream)))
+    return H
+
+
+class ShardedSolver:
+    """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
+
+    ``solve()`` = broadcast of the keypoint table from rank 0, local solve of this rank's
+    rows, all-gather of the H grid; afterwards ``self.H`` holds the full grid on every
+    rank (what a following sharded warp needs for its own rows, and what rank 0 writes).
+    """
+
+    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve):
+        self.pair, self.dev, self.dist, self.solve_fn = pair, dev, dist, solve_fn
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.rows, self.cols = pair.vertices.shape[:2]
+        self.cells_total = self.rows * self.cols
+        self.n = len(pair.src)
+        self.parts = row_partition(self.rows, self.world)
+        self.max_rows = max(b - a for a, b in self.parts)
+        a, b = self.parts[self.rank]
+        self.my_rows = (a, b)
+        self.vert = torch.from_numpy(np.ascontiguousarray(pair.vertices[a:b].reshape(-1, 2))).to(dev)
+        # rank 0 owns the host set-up; the others receive the result
+        self.table = torch.zeros((self.n, _native.TABLE_STRIDE), dtype=torch.float64, device=dev)
+        self.denorm = torch.zeros(_native.DENORM_DOUBLES, dtype=torch.float64, device=dev)
+        if self.rank == 0:
+            q = _native.host_prepare(pair.src, pair.dst)
+            self.table.copy_(torch.from_numpy(_native.host_build_table(pair.src, q["cf1"], q["cf2"])))
+            self.denorm.copy_(torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])))
+        self.H = torch.zeros((self.cells_total, 9), dtype=torch.float32, device=dev)
+        self._gather = torch.zeros((self.world, self.max_rows * self.cols, 9), dtype=torch.float32, device=dev)
+        self._mine = torch.zeros((self.max_rows * self.cols, 9), dtype=torch.float32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cells = self.cells_total
+
+    def solve(self, stream=None):
+        d = self.dist
+        if d is not None and self.world > 1:
+            d.broadcast(self.table, src=0)
+            d.broadcast(self.denorm, src=0)
+        a, b = self.my_rows
+        mine = self.solve_fn(self.table, self.denorm, self.vert, self.pair.gamma, self.pair.sigma)
+        if d is None or self.world == 1:
+            self.H.copy_(mine)
+            return self.H
+        self._mine[:(b - a) * self.cols].copy_(mine)
+        d.all_gather_into_tensor(self._gather.view(-1, 9), self._mine)
+        for r, (ra, rb) in enumerate(self.parts):      # drop the padding of uneven shards
+            self.H[ra * self.cols:rb * self.cols].copy_(self._gather[r, :(rb - ra) * self.cols])
+        return self.H
+
+    def warp(self, stream=None):
+        raise NotImplementedError("row-banded warp of one pair is not built yet (SURVEY.md 8e: "
+                                  "transfer-dominated); use --mode pairs")
+
+
+def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
+    """Independent pairs dealt round-robin to the ranks; returns, on rank 0, the list of
+    H grids in input order (``None`` elsewhere).  All pairs must share one mesh shape."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    mine = []
+    for k in range(rank, len(pairs), world):
+        p = pairs[k]
+        q = _native.host_prepare(p.src, p.dst)
+        table = torch.from_numpy(_native.host_build_table(p.src, q["cf1"], q["cf2"])).to(dev)
+        den = torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])).to(dev)
+        vert = torch.from_numpy(np.ascontiguousarray(p.vertices.reshape(-1, 2))).to(dev)
+        mine.append(solve_fn(table, den, vert, p.gamma, p.sigma))
+    if dist is None or world == 1:
+        return [h.cpu().numpy().reshape(p.vertices.shape[0], p.vertices.shape[1], 3, 3) for h, p in zip(mine, pairs)]
+    per_rank = (len(pairs) + world - 1) // world
+    cells = pairs[0].vertices.shape[0] * pairs[0].vertices.shape[1]
+    buf = torch.zeros((per_rank, cells, 9), dtype=torch.float32, device=dev)
+    for i, h in enumerate(mine):
+        buf[i].copy_(h)
+    out = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+    if dist.get_backend() == "nccl":
+        allbuf = torch.zeros((world,) + tuple(buf.shape), dtype=buf.dtype, device=dev)
+        dist.all_gather_into_tensor(allbuf.view(-1, cells, 9), buf)
+        out = list(allbuf) if rank == 0 else None
+    else:
+        dist.gather(buf, out, dst=0)
+    if rank != 0:
+        return None
+    rows, cols = pairs[0].vertices.shape[:2]
+    return [out[k % world][k // world].cpu().numpy().reshape(rows, cols, 3, 3) for k in range(len(pairs))]

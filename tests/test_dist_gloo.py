@@ -1,0 +1,124 @@
+"""The multi-GPU driver on two CPU ranks (gloo): partitioning, the table broadcast, the
+H-grid all-gather with uneven shards, pair round-robin and the final gather.  The
+compute is the oracle injected as ``solve_fn`` - the HIP engine cannot run here, and the
+point of these tests is the exchange logic."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_solve(table, denorm, vertices, gamma, sigma):
+    """CPU stand-in with the ``solve_fn`` contract, computed from the broadcast table
+    alone (so a rank that did not receive the table gets the wrong answer)."""
+    t = table.cpu().numpy()
+    den = denorm.cpu().numpy().reshape(4, 3, 3)
+    v = vertices.cpu().numpy()
+    if len(v) == 0:
+        return torch.zeros((0, 9), dtype=torch.float32)
+    from test_host_logic import MOMENT_INDEX
+    P = np.zeros((len(t), 9, 9))
+    for k, (i, j) in enumerate(MOMENT_INDEX):
+        P[:, i, j] = t[:, k]
+        P[:, j, i] = t[:, k]
+    P[:, 3:6, 3:6] = P[:, 0:3, 0:3]
+    s = t[:, 30:32]
+    d = np.sqrt((v[:, None, 0] - s[None, :, 0]) ** 2 + (v[:, None, 1] - s[None, :, 1]) ** 2)
+    w = np.exp(-(d * (1.0 / sigma ** 2)))
+    w[w < gamma] = gamma
+    M = ((w * w) @ P.reshape(len(t), 81)).reshape(-1, 9, 9)
+    _, vec = np.linalg.eigh(M)
+    h = vec[:, :, 0].reshape(-1, 3, 3)
+    h = den[2] @ (den[0] @ h @ den[1]) @ den[3]
+    h = h / h[:, 2:3, 2:3]
+    return torch.from_numpy(h.astype(np.float32).reshape(-1, 9))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, rows, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cvx_proj_amd.dist import ShardedSolver, solve_pairs
+        from cvx_proj_amd.synth import synth_pair
+        p = synth_pair(640, 480, 150, rows, seed=21)        # rows x rows mesh
+        p.vertices = p.vertices[:, :rows + 2] if rows > 3 else p.vertices   # non-square is fine
+        s = ShardedSolver(p, torch.device("cpu"), dist, solve_fn=oracle_solve)
+        if rank != 0:
+            assert float(s.table.abs().sum()) == 0.0            # only rank 0 holds the table before solve()
+        H = s.solve().numpy().copy()
+        assert float(s.table.abs().sum()) > 0.0                  # broadcast arrived
+        pairs = [synth_pair(320, 240, 60, 4, seed=100 + k) for k in range(5)]
+        grids = solve_pairs(pairs, torch.device("cpu"), dist, solve_fn=oracle_solve)
+        q.put((rank, s.parts, H, grids))
+    except Exception as e:          # surface the failure instead of letting the parent time out
+        import traceback
+        q.put((rank, "ERROR", traceback.format_exc(), None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows", [5, 8, 1])
+def test_sharded_solver_two_ranks(rows):
+    from oracle import apap_oracle as O
+    from cvx_proj_amd.synth import synth_pair
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, rows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert r[1] != "ERROR", r[2]
+    assert all(p.exitcode == 0 for p in procs)
+    p = synth_pair(640, 480, 150, rows, seed=21)
+    verts = p.vertices[:, :rows + 2] if rows > 3 else p.vertices
+    H_ref, _ = O.local_homography_fast(p.src, p.dst, verts, p.gamma, p.sigma)
+    for rank, parts, H, grids in res:
+        assert parts == res[0][1] and parts[0][0] == 0 and parts[-1][1] == verts.shape[0]
+        H = H.reshape(verts.shape[0], verts.shape[1], 3, 3)
+        assert O.reprojection_rmse_delta(H, H_ref, p.src).max() < 1e-6     # full grid on EVERY rank
+    assert np.array_equal(res[0][2], res[1][2])
+    assert res[1][3] is None
+    grids = res[0][3]
+    assert len(grids) == 5
+    for k, g in enumerate(grids):
+        pk = synth_pair(320, 240, 60, 4, seed=100 + k)
+        ref, _ = O.local_homography_fast(pk.src, pk.dst, pk.vertices, pk.gamma, pk.sigma)
+        assert O.reprojection_rmse_delta(g, ref, pk.src).max() < 1e-6, k
+
+
+def test_row_partition():
+    from cvx_proj_amd.dist import row_partition
+    assert row_partition(400, 8) == [(50 * r, 50 * r + 50) for r in range(8)]
+    assert row_partition(5, 2) == [(0, 3), (3, 5)]
+    assert row_partition(1, 2) == [(0, 1), (1, 1)]
+    parts = row_partition(203, 8)
+    assert parts[0][0] == 0 and parts[-1][1] == 203 and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+def test_hip_solve_refuses_cpu_tensors():
+    from cvx_proj_amd import _native
+    from cvx_proj_amd.dist import hip_solve
+    with pytest.raises(_native.ApapError):
+        hip_solve(torch.zeros((4, 32), dtype=torch.float64), torch.zeros(36, dtype=torch.float64),
+                  torch.zeros((2, 2), dtype=torch.float64), 0.5, 100.0)
