@@ -20,6 +20,7 @@ OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSP
 TABLE_STRIDE = 32
 DENORM_DOUBLES = 36
 VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA = 0, 1, 2
+EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 
 
 class ApapError(RuntimeError):
@@ -43,6 +44,7 @@ SIGNATURES = {
     "apap_version": (C.c_char_p, []),
     "apap_device_count": (C.c_int, []),
     "apap_set_solver_variant": (C.c_int, [C.c_int]),
+    "apap_set_eigen_solver": (C.c_int, [C.c_int]),
     "apap_profile_enable": (C.c_int, [C.c_int]),
     "apap_profile_read": (C.c_int, [_f32p, _i32p]),
     "apap_host_prepare": (C.c_int, [_f32p, _f32p, C.c_int] + [_f32p] * 10),

@@ -14,6 +14,7 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is written fma().
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "apap_internal.h"
@@ -25,13 +26,79 @@ constexpr int kWave = 64;
 
 // weight of one keypoint for one cell: max(exp(-|v - s| / sigma^2), gamma), float64 like
 // apap.py:150-152 (np.sqrt and np.exp on float64).
+//
+// sqrt and exp are the device library's algorithms (v_rsq_f64 + Goldschmidt with two
+// residual corrections; Cody-Waite reduction + degree-11 polynomial + v_ldexp_f64, same
+// constants and operation order, hence the same bits) with their range guards replaced
+// by what this call site needs: 10 + 18 instructions instead of 17 + 22.
+//   * d2 is clamped below at 1e-300 instead of special-casing 0: sqrt gives 1e-150 and
+//     exp(-1e-150/sigma^2) == 1.0 exactly, the value for distance 0.
+//   * the exponent argument is clamped at -1100 (exp underflows to 0 there).
+//   * inf/NaN coordinates are not propagated as NaN (the reference would produce NaN
+//     matrices for them).
+__device__ __forceinline__ double sqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    d = fma(-g, g, x);
+    return fma(d, h, g);
+}
+
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -1100.0);
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+0);       // log2(e)
+    double r = fma(n, -0x1.62e42fefa39efp-1, x);                        // -ln2 high
+    r = fma(n, -0x1.abc9e3b39803fp-56, r);                              // -ln2 low
+    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma(r, p, 0x1.71dee623fde64p-19);
+    p = fma(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma(r, p, 0x1.a01a014761f6ep-13);
+    p = fma(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(r, p, 0x1.1111111122322p-7);
+    p = fma(r, p, 0x1.55555555502a1p-5);
+    p = fma(r, p, 0x1.5555555555511p-3);
+    p = fma(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+
 __device__ __forceinline__ double cell_weight(double vx, double vy, double sx, double sy,
                                               double inv_sigma, double gamma) {
     const double dx = vx - sx;
     const double dy = vy - sy;
-    const double dist = sqrt(dx * dx + dy * dy);
-    const double w = exp(-(dist * inv_sigma));
-    return (w < gamma) ? gamma : w;
+    const double d2 = fmax(dx * dx + dy * dy, 1e-300);
+    const double dist = sqrt_pos(d2);
+    const double w = exp_nonpos(-(dist * inv_sigma));
+    return fmax(w, gamma);
+}
+
+// w^2 for K1, where the weight itself is not an output: 31 fp64 instructions instead of
+// 37.  max(exp(-t), gamma)^2 = max(exp(-2t), gamma^2); the squared distance is one
+// multiply-add chain that carries the 1e-300 guard; sqrt keeps one residual correction
+// (error < 1 ulp instead of correctly rounded).  Each change moves w^2 by at most a few
+// ulp of float64 (1e-16 relative) - eight orders below what the float32 H can see; the
+// weight tensor that callers can ask for still comes from cell_weight().
+//   inv_sigma2 = 2 / sigma^2,  gamma2 = gamma > 0 ? gamma * gamma : 0
+__device__ __forceinline__ double cell_weight_sq(double vx, double vy, double sx, double sy,
+                                                 double inv_sigma2, double gamma2) {
+    const double dx = vx - sx;
+    const double dy = vy - sy;
+    const double x = fma(dx, dx, fma(dy, dy, 1e-300));
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return fmax(exp_nonpos(-(g * inv_sigma2)), gamma2);
 }
 
 // --------------------------------------------------------------------------------
@@ -44,7 +111,7 @@ __device__ __forceinline__ double cell_weight(double vx, double vy, double sx, d
 // --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
-                                                       int cells_pad, double gamma, double inv_sigma,
+                                                       int cells_pad, double gamma2, double inv_sigma2,
                                                        int pts_per_split, double *__restrict__ moments) {
     __shared__ double red[3][kMoments][kWave];
     const int lane = threadIdx.x & 63;
@@ -62,12 +129,27 @@ __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict_
 #pragma unroll
     for (int j = 0; j < kMoments; ++j) acc[j] = 0.0;
 
+    // The keypoint's (x, y) is fetched one iteration ahead: scalar loads return out of
+    // order, so the only usable wait is lgkmcnt(0); with x, y already in SGPRs the weight
+    // (~40 VALU instructions) runs while this iteration's 30 products are in flight.
+    double sx = 0.0, sy = 0.0;
+    if (p0 < p1) {
+        sx = table[(size_t)p0 * APAP_TABLE_STRIDE + 30];
+        sy = table[(size_t)p0 * APAP_TABLE_STRIDE + 31];
+    }
+    // Drain the prologue's loads here, or the compiler's wait for them lands inside the
+    // loop right after the prefetch is issued and serialises it.  0x0070 = vmcnt(0) lgkmcnt(0).
+    __builtin_amdgcn_s_waitcnt(0x0070);
     for (int p = p0; p < p1; ++p) {
         const double *__restrict__ row = table + (size_t)p * APAP_TABLE_STRIDE;
-        const double w = cell_weight(vx, vy, row[30], row[31], inv_sigma, gamma);
-        const double w2 = w * w;
+        const double *__restrict__ nxt = table + (size_t)min(p + 1, p1 - 1) * APAP_TABLE_STRIDE;
+        const double nsx = nxt[30], nsy = nxt[31];
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the weight computation
+        const double w2 = cell_weight_sq(vx, vy, sx, sy, inv_sigma2, gamma2);
 #pragma unroll
         for (int j = 0; j < kMoments; ++j) acc[j] = fma(w2, row[j], acc[j]);
+        sx = nsx;
+        sy = nsy;
     }
 
     if (wave > 0) {
@@ -108,7 +190,7 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 256 + ((c ^ ((
 
 __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
-                                                       int cells_pad, double gamma, double inv_sigma,
+                                                       int cells_pad, double gamma2, double inv_sigma2,
                                                        int pts_per_split, double *__restrict__ moments) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
     const int tid = threadIdx.x;
@@ -152,6 +234,10 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
         store_chunk(0);
     }
     __syncthreads();
+    // Drain the prologue's loads (vertex, first chunk) here: otherwise the compiler's wait
+    // for the vertex registers lands inside the step loop as vmcnt(0) and also waits for
+    // the NEXT chunk's prefetch, which is meant to fly during the MFMAs.
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk(c + 1);
         const unsigned char *buf = lds[c & 1];
@@ -162,8 +248,7 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
             const double2 xy = *reinterpret_cast<const double2 *>(buf + lds_off(r, 30));
             const double b0 = *reinterpret_cast<const double *>(buf + lds_off(r, col));
             const double b1 = *reinterpret_cast<const double *>(buf + lds_off(r, 16 + col));
-            const double w = cell_weight(vx, vy, xy.x, xy.y, inv_sigma, gamma);
-            const double w2 = w * w;
+            const double w2 = cell_weight_sq(vx, vy, xy.x, xy.y, inv_sigma2, gamma2);
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
         }
@@ -247,6 +332,139 @@ __device__ __forceinline__ void mul3(const double *x, const double *y, double *o
 
 constexpr int kMaxSweeps = 15;
 
+// Eigenvector of the (pick_rank)-th smallest eigenvalue by cyclic Jacobi.  `a` is
+// destroyed.  Which eigenvector: the reference takes the LAST row of the V^T that the thin
+// SVD of the 2n x 9 system returns, singular values sorted descending (apap.py:160-161).
+// For 2n >= 9 that is the smallest eigenvalue of A^T W^2 A (pick_rank 0); for fewer rows
+// the thin V^T has only 2n rows and its last one belongs to the (9 - 2n)-th smallest
+// eigenvalue.  Rank = number of strictly smaller diagonal entries, ties broken by index.
+__device__ __forceinline__ void jacobi_eigvec(double (&a)[45], int pick_rank, double (&h)[9]) {
+    double v[81];
+#pragma unroll
+    for (int k = 0; k < 81; ++k) v[k] = (k % 10 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+        jacobi_sweep(a, v);
+        double off2 = 0.0, trace = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            trace += fabs(a[tri(i, i)]);
+#pragma unroll
+            for (int j = i + 1; j < 9; ++j) off2 = fma(a[tri(i, j)], a[tri(i, j)], off2);
+        }
+        // quadratic convergence: 1e-17 relative is reached one sweep after ~1e-8.
+        // NaN input never converges and stops at kMaxSweeps.
+        const bool done = off2 <= 1e-34 * trace * trace;
+        if (__all(done)) break;
+    }
+    int best = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j != i) {
+                const double di = a[tri(i, i)], dj = a[tri(j, j)];
+                rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+            }
+        }
+        best = (rank == pick_rank) ? i : best;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double x = v[9 * k];
+#pragma unroll
+        for (int c = 1; c < 9; ++c) x = (best == c) ? v[9 * k + c] : x;
+        h[k] = x;
+    }
+}
+
+// Smallest eigenvector by inverse iteration on an in-register L D L^T factorisation
+// (no pivoting: the matrix is a Gram matrix).  The gap of these systems is huge
+// (lambda_9 / lambda_8 ~ 1e-5 on image data, ~1e-3 on the 120-point fixtures), so the
+// iteration contracts by that factor per step; it runs until two successive unit vectors
+// agree to 1e-14 (sign-adjusted).  Returns false when a pivot is not positive/finite or
+// the iteration has not converged in kMaxInvIt steps - the caller then falls back to
+// Jacobi, which needs no gap.  ~0.9k instructions against ~30k for six Jacobi sweeps.
+constexpr int kMaxInvIt = 12;
+
+__host__ __device__ constexpr int low(int i, int j) { return i * (i - 1) / 2 + j; }  // strict lower, i > j
+
+__device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double (&h)[9]) {
+    double l[36], d[9], rd[9];  // unit lower factor, pivots and their reciprocals
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double t[9];  // t[k] = l(j,k) * d[k]
+        double dj = a[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (k < j) {
+                t[k] = l[low(j, k)] * d[k];
+                dj = fma(-l[low(j, k)], t[k], dj);
+            }
+        }
+        ok = ok && (dj > 0.0) && (dj < 1e300);
+        d[j] = dj;
+        rd[j] = 1.0 / dj;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            if (i > j) {
+                double sum = a[tri(j, i)];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                    if (k < j) sum = fma(-l[low(i, k)], t[k], sum);
+                l[low(i, j)] = sum * rd[j];
+            }
+        }
+    }
+    double v[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = 1.0 / 3.0;
+    bool done = false;
+    for (int it = 0; it < kMaxInvIt; ++it) {
+        double y[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {  // L z = v
+            double sum = v[i];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k < i) sum = fma(-l[low(i, k)], y[k], sum);
+            y[i] = sum;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) y[i] *= rd[i];  // D
+#pragma unroll
+        for (int i = 8; i >= 0; --i) {  // L^T y = z
+            double sum = y[i];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                if (k > i) sum = fma(-l[low(k, i)], y[k], sum);
+            y[i] = sum;
+        }
+        double nrm2 = 0.0, dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            nrm2 = fma(y[i], y[i], nrm2);
+            dot = fma(y[i], v[i], dot);
+        }
+        const double scale = copysign(1.0, dot) / sqrt(nrm2);
+        double change = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const double yn = y[i] * scale;
+            change = fmax(change, fabs(yn - v[i]));
+            v[i] = yn;
+        }
+        done = change <= 1e-14;  // false for NaN
+        if (__all(done || !ok)) break;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) h[k] = v[k];
+    return ok && done;
+}
+
+// K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
+template <bool kUseInverseIteration>
 __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
                                                      int cells, int cells_pad,
                                                      const double *__restrict__ denorm, int pick_rank,
@@ -255,10 +473,11 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
     const int cc = min(cell, cells - 1);
     double m[kMoments];
 #pragma unroll
-    for (int j = 0; j < kMoments; ++j) {
-        double s = moments[(size_t)j * cells_pad + cc];
-        for (int g = 1; g < splits; ++g) s += moments[((size_t)g * kMoments + j) * cells_pad + cc];
-        m[j] = s;
+    for (int j = 0; j < kMoments; ++j) m[j] = moments[(size_t)j * cells_pad + cc];
+    for (int g = 1; g < splits; ++g) {  // slabs of the keypoint splits, fixed order
+        const double *slab = moments + (size_t)g * kMoments * cells_pad + cc;
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) m[j] += slab[(size_t)j * cells_pad];
     }
     // A^T W^2 A = [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]  (3x3 blocks)
     double a[45];
@@ -278,51 +497,14 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
     a[tri(6, 6)] = m[24]; a[tri(6, 7)] = m[25]; a[tri(6, 8)] = m[26];
     a[tri(7, 7)] = m[27]; a[tri(7, 8)] = m[28]; a[tri(8, 8)] = m[29];
 
-    double v[81];
-#pragma unroll
-    for (int k = 0; k < 81; ++k) v[k] = (k % 10 == 0) ? 1.0 : 0.0;
-
-    for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-        jacobi_sweep(a, v);
-        double off2 = 0.0, trace = 0.0;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            trace += fabs(a[tri(i, i)]);
-#pragma unroll
-            for (int j = i + 1; j < 9; ++j) off2 = fma(a[tri(i, j)], a[tri(i, j)], off2);
-        }
-        // quadratic convergence: 1e-17 relative is reached one sweep after ~1e-8.
-        // NaN input never converges and stops at kMaxSweeps.
-        const bool done = off2 <= 1e-34 * trace * trace;
-        if (__all(done)) break;
-    }
-
-    // Which eigenvector: the reference takes the LAST row of the V^T that the thin SVD
-    // of the 2n x 9 system returns, singular values sorted descending (apap.py:160-161).
-    // For 2n >= 9 that is the smallest eigenvalue of A^T W^2 A (pick_rank 0); for fewer
-    // rows the thin V^T has only 2n rows and the last one belongs to the
-    // (9 - 2n)-th smallest eigenvalue.  Rank = number of strictly smaller diagonal
-    // entries, ties broken by index.
-    int best = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        int rank = 0;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            if (j != i) {
-                const double di = a[tri(i, i)], dj = a[tri(j, j)];
-                rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
-            }
-        }
-        best = (rank == pick_rank) ? i : best;
-    }
     double h[9];
+    bool have = false;
+    if (kUseInverseIteration && pick_rank == 0) have = inverse_iteration(a, h);
+    if (!__all(have)) {  // rare: no spectral gap, rank-deficient system, n < 5
+        double hj[9];
+        jacobi_eigvec(a, pick_rank, hj);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        double x = v[9 * k];
-#pragma unroll
-        for (int c = 1; c < 9; ++c) x = (best == c) ? v[9 * k + c] : x;
-        h[k] = x;
+        for (int k = 0; k < 9; ++k) h[k] = have ? h[k] : hj[k];
     }
     double t1[9], t2[9];
     mul3(denorm, h, t1);        // inv(C2) . h
@@ -457,64 +639,168 @@ __global__ __launch_bounds__(256) void k_cell_lut(const double *__restrict__ mes
     lut[t] = c;
 }
 
+// Warp set-up in ONE launch: blocks [0, inv_blocks) invert 256 cells each; the following
+// blocks build the lookup table, 1024 canvas rows (then columns) per block.
+// "first k with i < edges[k]" is the first k whose RUNNING MAXIMUM exceeds i (an edge
+// that is not above i cannot be above anything a later comparison still needs), and the
+// running maximum is monotone: an inclusive max-scan of the edges in LDS, then a binary
+// search per index.  Valid for any edge order, like the reference's np.where scan.
+constexpr int kMaxEdges = 4096;  // per axis; larger meshes take the linear-scan kernel
+
+__global__ __launch_bounds__(256) void k_warp_setup(const float *__restrict__ H, int cells,
+                                                    float *__restrict__ hinv_pad,
+                                                    float *__restrict__ hinv_dense, int inv_blocks,
+                                                    const double *__restrict__ mesh_w, int n_w,
+                                                    const double *__restrict__ mesh_h, int n_h,
+                                                    int mesh_rows, int mesh_cols, int final_w, int final_h,
+                                                    int *__restrict__ lut, int *status) {
+    __shared__ double pm[2][kMaxEdges];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < inv_blocks) {
+        const int cell = blockIdx.x * 256 + tid;
+        if (cell >= cells) return;
+        double m[9], r[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
+        if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
+        float4 *p = reinterpret_cast<float4 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+        p[0] = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+        p[1] = make_float4((float)r[4], (float)r[5], (float)r[6], (float)r[7]);
+        p[2] = make_float4((float)r[8], 0.0f, 0.0f, 0.0f);
+        if (hinv_dense) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (float)r[k];
+        }
+        return;
+    }
+    const int row_blocks = (final_h + 1023) / 1024;
+    const int b = blockIdx.x - inv_blocks;
+    const bool is_row = b < row_blocks;
+    const double *edges = is_row ? mesh_h : mesh_w;
+    const int n_e = is_row ? n_h : n_w;
+    const int ncell = is_row ? mesh_rows : mesh_cols;
+    const int count = is_row ? final_h : final_w;
+    const int base = (is_row ? b : b - row_blocks) * 1024;
+    // inclusive max-scan (Hillis-Steele, ping-pong buffers)
+    for (int i = tid; i < n_e; i += 256) pm[0][i] = edges[i];
+    __syncthreads();
+    int cur = 0;
+    for (int off = 1; off < n_e; off <<= 1) {
+        for (int i = tid; i < n_e; i += 256) {
+            const double v = pm[cur][i];
+            pm[cur ^ 1][i] = (i >= off) ? fmax(v, pm[cur][i - off]) : v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const double *run = pm[cur];
+    for (int q = tid; q < 1024; q += 256) {
+        const int idx = base + q;
+        if (idx >= count) break;
+        const double x = (double)idx;
+        int lo = 0, hi = n_e;  // first k in [0, n_e) with x < run[k]; n_e = none
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (x < run[mid]) hi = mid; else lo = mid + 1;
+        }
+        int c = lo - 1;
+        bool bad = lo >= n_e;
+        if (c < 0) c += ncell;  // Python's index -1
+        bad = bad || c < 0 || c >= ncell;
+        if (bad) { atomicOr(status, apap::kStatusIndex); c = 0; }
+        lut[(is_row ? 0 : final_h) + idx] = c;
+    }
+}
+
 struct __attribute__((packed, aligned(4))) Bytes12 {
     unsigned int a, b, c;
 };
 
 // target coordinate of canvas pixel (i, j) through the (already inverted) cell matrix:
-// float64 FMA chain in the order h0*x + h1*y + h2, then two true divisions
-// (apap.py:172-184,211-213: float32 H^-1 promoted to float64 by the int64 point).
-__device__ __forceinline__ void target_of(const float *__restrict__ hinv_pad, int cell, double x,
-                                          double y, double &tx, double &ty) {
-    const float4 *hp = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
-    const float4 r0 = hp[0], r1 = hp[1], r2 = hp[2];
+// float64 FMA chain in the order h0*x + h1*y + h2, then the two divisions by the third
+// component (apap.py:172-184,211-213: float32 H^-1 promoted to float64 by the int64
+// point).  The two quotients share one reciprocal (v_rcp_f64 + two Newton steps) and get
+// one residual correction each - the Markstein sequence, which returns the correctly
+// rounded quotient the reference's true division produces (checked against the oracle's
+// coordinates in tests: equal).
+__device__ __forceinline__ void target_from(const float4 r0, const float4 r1, const float4 r2, double x,
+                                            double y, double &tx, double &ty) {
     const double t0 = fma((double)r0.z, 1.0, fma((double)r0.y, y, (double)r0.x * x));
     const double t1 = fma((double)r1.y, 1.0, fma((double)r1.x, y, (double)r0.w * x));
     const double t2 = fma((double)r2.x, 1.0, fma((double)r1.w, y, (double)r1.z * x));
-    tx = t0 / t2;
-    ty = t1 / t2;
+    double r = __builtin_amdgcn_rcp(t2);
+    r = fma(fma(-t2, r, 1.0), r, r);
+    r = fma(fma(-t2, r, 1.0), r, r);
+    const double q0 = t0 * r, q1 = t1 * r;
+    tx = fma(fma(-t2, q0, t0), r, q0);
+    ty = fma(fma(-t2, q1, t1), r, q1);
 }
 
-__device__ __forceinline__ unsigned int gather_rgb(const uint8_t *__restrict__ img, int img_w,
-                                                   int img_h, size_t img_bytes, double tx, double ty) {
-    // strict inequalities and truncation, apap.py:214-215; NaN fails every comparison
-    if (!(0.0 < tx && tx < (double)img_w && 0.0 < ty && ty < (double)img_h)) return 0u;
-    const int ix = (int)tx, iy = (int)ty;
-    const size_t o = ((size_t)iy * img_w + ix) * 3;
-    unsigned int v;
-    if (o + 4 <= img_bytes) {
-        __builtin_memcpy(&v, img + o, 4);  // one unaligned dword
-        return v & 0x00ffffffu;
-    }
-    v = (unsigned int)img[o] | ((unsigned int)img[o + 1] << 8) | ((unsigned int)img[o + 2] << 16);
-    return v;
+__device__ __forceinline__ void target_of(const float *__restrict__ hinv_pad, int cell, double x,
+                                          double y, double &tx, double &ty) {
+    const float4 *hp = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+    target_from(hp[0], hp[1], hp[2], x, y, tx, ty);
 }
 
 // K3: backward warp.  One thread = 4 consecutive canvas pixels in flat order = 12
 // contiguous output bytes = one global_store_dwordx3; a wave writes 768 contiguous
-// bytes.  The gather reads 3 bytes per pixel; neighbouring lanes read neighbouring
-// source pixels because local homographies are close to the global one.
+// bytes.  The gather reads 3 bytes per pixel with one unaligned dword load; neighbouring
+// lanes read neighbouring source pixels because local homographies are close to the
+// global one.  The body is branch-free and staged (all lookups, then all H^-1 loads,
+// then arithmetic, then all gathers) so that a thread keeps 8 / 12 / 4 loads in flight
+// instead of walking a dependent chain per pixel: the kernel is latency-bound, not
+// issue-bound.  Requires img_bytes >= 4.
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, int img_h, int img_w,
                                               const float *__restrict__ hinv_pad, int mesh_cols,
                                               const int *__restrict__ lut, int final_w, int final_h,
                                               int off_x, int off_y, uint8_t *__restrict__ out) {
     const size_t total = (size_t)final_w * final_h;
-    const size_t img_bytes = (size_t)img_h * img_w * 3;
+    const size_t last = (size_t)img_h * img_w * 3 - 4;
     const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (g >= total) return;
-    int i = (int)(g / final_w);
-    int j = (int)(g - (size_t)i * final_w);
+    int ii[4], jj[4];
+    {
+        int i = (int)(g / final_w);
+        int j = (int)(g - (size_t)i * final_w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ii[k] = min(i, final_h - 1);  // only the last thread can run past the canvas
+            jj[k] = j;
+            if (++j == final_w) { j = 0; ++i; }
+        }
+    }
+    int cell[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cell[k] = lut[ii[k]] * mesh_cols + lut[final_h + jj[k]];
+    float4 h0[4], h1[4], h2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 *hp = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[k] * APAP_HINV_STRIDE);
+        h0[k] = hp[0];
+        h1[k] = hp[1];
+        h2[k] = hp[2];
+    }
+    size_t off[4];
+    bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double tx, ty;
+        target_from(h0[k], h1[k], h2[k], (double)(jj[k] - off_x), (double)(ii[k] - off_y), tx, ty);
+        // strict inequalities and truncation, apap.py:214-215; NaN fails every comparison
+        ok[k] = 0.0 < tx && tx < (double)img_w && 0.0 < ty && ty < (double)img_h;
+        const int ix = ok[k] ? (int)tx : 0, iy = ok[k] ? (int)ty : 0;
+        off[k] = ((size_t)iy * img_w + ix) * 3;
+    }
     unsigned int px[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        px[k] = 0u;
-        if (g + k < total) {
-            const int cell = lut[i] * mesh_cols + lut[final_h + j];
-            double tx, ty;
-            target_of(hinv_pad, cell, (double)(j - off_x), (double)(i - off_y), tx, ty);
-            px[k] = gather_rgb(img, img_w, img_h, img_bytes, tx, ty);
-        }
-        if (++j == final_w) { j = 0; ++i; }
+        // the dword at the pixel's first byte; for the image's very last pixel read the
+        // dword one byte earlier and shift, so that no byte beyond the image is touched
+        const size_t oc = off[k] < last ? off[k] : last;
+        unsigned int v;
+        __builtin_memcpy(&v, img + oc, 4);
+        v >>= 8 * (unsigned)(off[k] - oc);
+        px[k] = ok[k] ? (v & 0x00ffffffu) : 0u;
     }
     uint8_t *o = out + g * 3;
     if (g + 4 <= total) {
@@ -592,6 +878,7 @@ inline int hip_fail(hipError_t e, const char *what) {
 }
 
 int g_variant = APAP_VARIANT_AUTO;
+int g_eigen = APAP_EIGEN_AUTO;
 
 // ---- optional per-kernel timing with HIP events on the launch stream ----
 struct ProfSpan {
@@ -624,15 +911,20 @@ namespace apap {
 
 SolvePlan plan_solve(int n, int cells, int variant) {
     SolvePlan p{};
-    if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_VALU;
+    if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_MFMA;  // measured faster on C2-C4, DESIGN.md
     p.variant = variant;
     p.cell_tiles = (cells + kWave - 1) / kWave;  // both variants: 64 cells per 4-wave block
     p.cells_pad = p.cell_tiles * kWave;
-    // Fill the chip (256 CUs x 4 SIMDs): aim at >= 2 waves per SIMD.  Small meshes split
+    // Fill the chip (256 CUs x 4 SIMDs): aim at >= 4 waves per SIMD (also evens out the
+    // blocks-per-CU imbalance: 2500 waves leave SIMDs with 2 or 3, 5000 with 4 or 5).  Small meshes split
     // the keypoint list over grid.y; each split writes its own moment slab and K2 adds
     // the slabs in a fixed order.  Keep >= 256 keypoints per split.
     int splits = 1;
-    const int want_waves = 2048;
+    static const int want_waves = [] {
+        const char *e = getenv("APAP_WANT_WAVES");  // tuning knob for tools/sweep.py
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 4096;
+    }();
     while (splits < 16 && p.cell_tiles * 4 * splits < want_waves && n / (splits * 2) >= 256) splits *= 2;
     int pps = (n + splits - 1) / splits;
     pps = (pps + 3) / 4 * 4;
@@ -649,6 +941,12 @@ extern "C" {
 int apap_set_solver_variant(int variant) {
     const int prev = g_variant;
     if (variant == APAP_VARIANT_AUTO || variant == APAP_VARIANT_VALU || variant == APAP_VARIANT_MFMA) g_variant = variant;
+    return prev;
+}
+
+int apap_set_eigen_solver(int which) {
+    const int prev = g_eigen;
+    if (which == APAP_EIGEN_AUTO || which == APAP_EIGEN_JACOBI || which == APAP_EIGEN_INVERSE_ITERATION) g_eigen = which;
     return prev;
 }
 
@@ -669,21 +967,27 @@ int apap_solve_device(const double *d_table, int n, const double *d_vertices, in
         return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes, p.moment_bytes);
     hipStream_t s = (hipStream_t)stream;
     const double inv_sigma = 1.0 / (sigma * sigma);  // apap.py:142
+    const double inv_sigma2 = 2.0 * inv_sigma;       // K1 evaluates exp(-2 d / sigma^2) = w^2
+    const double gamma2 = gamma > 0.0 ? gamma * gamma : 0.0;
     double *moments = (double *)d_work;
     {
     ProfScope prof(APAP_PROF_ASSEMBLE, s);
     if (p.variant == APAP_VARIANT_MFMA)
         hipLaunchKernelGGL(k_assemble_mfma, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
-                           cells, p.cells_pad, gamma, inv_sigma, p.pts_per_split, moments);
+                           cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments);
     else
         hipLaunchKernelGGL(k_assemble_valu, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
-                           cells, p.cells_pad, gamma, inv_sigma, p.pts_per_split, moments);
+                           cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments);
     }
     const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
     {
         ProfScope prof(APAP_PROF_EIGEN, s);
-        hipLaunchKernelGGL(k_eigen_denorm, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
-                           p.cells_pad, d_denorm, pick_rank, d_H);
+        if (g_eigen == APAP_EIGEN_JACOBI)
+            hipLaunchKernelGGL(k_eigen_denorm<false>, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
+                               p.cells_pad, d_denorm, pick_rank, d_H);
+        else
+            hipLaunchKernelGGL(k_eigen_denorm<true>, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
+                               p.cells_pad, d_denorm, pick_rank, d_H);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
@@ -724,15 +1028,25 @@ static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, cons
     const size_t hinv_bytes = (((size_t)cells * APAP_HINV_STRIDE * sizeof(float) + 255) / 256) * 256;
     *hinv_pad = (float *)d_work;
     *lut = (int *)((char *)d_work + hinv_bytes);
-    {
+    if (n_w <= kMaxEdges && n_h <= kMaxEdges) {
+        // one launch: cell inverses + lookup table (reported under the INVERT slot)
         ProfScope prof(APAP_PROF_INVERT, s);
-        hipLaunchKernelGGL(k_invert_cells, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
-                           d_Hinv_out, d_status);
-    }
-    {
-        ProfScope prof(APAP_PROF_LUT, s);
-        hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
-                           d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
+        const int inv_blocks = (cells + 255) / 256;
+        const int lut_blocks = (final_h + 1023) / 1024 + (final_w + 1023) / 1024;
+        hipLaunchKernelGGL(k_warp_setup, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+                           d_Hinv_out, inv_blocks, d_mesh_w, n_w, d_mesh_h, n_h, mesh_rows, mesh_cols, final_w,
+                           final_h, *lut, d_status);
+    } else {
+        {
+            ProfScope prof(APAP_PROF_INVERT, s);
+            hipLaunchKernelGGL(k_invert_cells, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+                               d_Hinv_out, d_status);
+        }
+        {
+            ProfScope prof(APAP_PROF_LUT, s);
+            hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
+                               d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
+        }
     }
     return APAP_OK;
 }
@@ -743,7 +1057,8 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream) {
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
-    if (img_h < 1 || img_w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size");
+    if (img_h < 1 || img_w < 1 || (size_t)img_h * img_w < 2)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size (need at least 2 pixels)");
     hipStream_t s = (hipStream_t)stream;
     float *hinv_pad;
     int *lut;

@@ -56,6 +56,12 @@ extern "C" {
 #define APAP_VARIANT_VALU 1 /* one lane per cell, fp64 FMA accumulation            */
 #define APAP_VARIANT_MFMA 2 /* v_mfma_f64_16x16x4_f64 accumulation, table via LDS  */
 
+/* Eigen-solvers of K2 (apap_set_eigen_solver). */
+#define APAP_EIGEN_AUTO 0              /* = inverse iteration with Jacobi fallback          */
+#define APAP_EIGEN_JACOBI 1            /* cyclic Jacobi sweeps only                         */
+#define APAP_EIGEN_INVERSE_ITERATION 2 /* LDL^T inverse iteration; Jacobi for cells without a
+                                          spectral gap, rank-deficient systems and n < 5     */
+
 /* Kernel slots of apap_profile_read. */
 #define APAP_PROF_ASSEMBLE 0 /* K1: weighted moment sums A^T W^2 A      */
 #define APAP_PROF_EIGEN 1    /* K2: Jacobi eigen-solve + de-normalise   */
@@ -71,6 +77,8 @@ const char *apap_version(void);
 int apap_device_count(void);
 /* Select the assembly kernel; returns the previous value.  Process-wide. */
 int apap_set_solver_variant(int variant);
+/* Select the 9x9 eigen-solver; returns the previous value.  Process-wide. */
+int apap_set_eigen_solver(int which);
 
 /* Per-kernel timing.  While enabled, the "_device" entry points bracket every kernel
  * with HIP events recorded on the launch stream.  apap_profile_read waits for them and

@@ -41,6 +41,30 @@ __global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// one MFMA (1024 lane-FMAs) + 16 independent v_fma_f64 (1024 lane-FMAs) per iteration:
+// if the f64 matrix pipe and the f64 vector ALU were separate units the pair would take
+// max(), if they share the DP-FMA hardware it takes the sum.
+__global__ __launch_bounds__(256) void k_mixed(double *out, int iters, double a, double b) {
+    double4_t acc[2] = {double4_t{0, 0, 0, 0}, double4_t{0, 0, 0, 0}};
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 1e-3 + i;
+    const double av = a + threadIdx.x * 1e-6, bv = b + threadIdx.x * 1e-6;
+    for (int it = 0; it < iters; ++it) {
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[0], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = fma(x[i], a, b);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[1], 0, 0, 0);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) x[i] = fma(x[i], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[i];
+    s += acc[0][0] + acc[0][1] + acc[0][2] + acc[0][3] + acc[1][0] + acc[1][1] + acc[1][2] + acc[1][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename F>
 double time_ms(F launch, int reps) {
     hipEvent_t e0, e1;
@@ -81,6 +105,14 @@ int main() {
         const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
         const double flops = 2.0 * 16 * 16 * 4 * ACC * iters * (double)blocks * (threads / 64);
         printf("v_mfma_f64_16x16x4_f64 (1 dependent acc/wave, 8 waves/SIMD): %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+    }
+    {
+        const int it2 = iters / 2;
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_mixed, dim3(blocks), dim3(threads), 0, 0, out, it2, 0.999999, 1e-9); }, 5);
+        const double f_mfma = 2.0 * 16 * 16 * 4 * 2 * it2 * (double)blocks * (threads / 64);
+        const double f_valu = 2.0 * 16 * it2 * (double)blocks * threads;
+        printf("mixed 2 MFMA + 16 v_fma_f64 per iteration: %.3f ms  MFMA part %.2f + VALU part %.2f = %.2f TFLOP/s\n", ms,
+               f_mfma / ms / 1e9, f_valu / ms / 1e9, (f_mfma + f_valu) / ms / 1e9);
     }
     hipFree(out);
     return 0;
