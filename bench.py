@@ -130,8 +130,8 @@ def main():
     ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--mode", default="pairs", choices=["pairs", "cells"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cells", type=int, default=6000)
-    ap.add_argument("--cpu-rows", type=int, default=96)
+    ap.add_argument("--cpu-cells", type=int, default=40000)
+    ap.add_argument("--cpu-rows", type=int, default=400)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

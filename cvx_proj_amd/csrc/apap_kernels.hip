@@ -750,35 +750,55 @@ __device__ __forceinline__ void target_of(const float *__restrict__ hinv_pad, in
 // then arithmetic, then all gathers) so that a thread keeps 8 / 12 / 4 loads in flight
 // instead of walking a dependent chain per pixel: the kernel is latency-bound, not
 // issue-bound.  Requires img_bytes >= 4.
+template <int kGather>
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, int img_h, int img_w,
                                               const float *__restrict__ hinv_pad, int mesh_cols,
                                               const int *__restrict__ lut, int final_w, int final_h,
                                               int off_x, int off_y, uint8_t *__restrict__ out) {
-    const size_t total = (size_t)final_w * final_h;
+    // 32-bit pixel indices (the launcher refuses canvases of 2^31 pixels or more): a
+    // 64-bit division here expands into ~100 instructions with branches
+    const unsigned total = (unsigned)final_w * (unsigned)final_h;
     const size_t last = (size_t)img_h * img_w * 3 - 4;
-    const size_t g = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const unsigned g = (blockIdx.x * 256u + threadIdx.x) * 4u;
     if (g >= total) return;
     int ii[4], jj[4];
     {
-        int i = (int)(g / final_w);
-        int j = (int)(g - (size_t)i * final_w);
+        int i = (int)(g / (unsigned)final_w);
+        int j = (int)(g - (unsigned)i * (unsigned)final_w);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ii[k] = min(i, final_h - 1);  // only the last thread can run past the canvas
+            ii[k] = min(i, final_h - 1);  // only the last group can run past the canvas
             jj[k] = j;
             if (++j == final_w) { j = 0; ++i; }
         }
     }
+    // Lookups.  The four pixels share a canvas row unless the group wraps, so two row
+    // lookups (first and last pixel) serve all four.
+    const int r0 = lut[ii[0]], r3 = lut[ii[3]];
     int cell[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cell[k] = lut[ii[k]] * mesh_cols + lut[final_h + jj[k]];
+    for (int k = 0; k < 4; ++k) cell[k] = (ii[k] == ii[0] ? r0 : r3) * mesh_cols + lut[final_h + jj[k]];
+    // H^-1 of the first and the last pixel's cells; the two in between almost always sit in
+    // one of those (cell indices are monotone along a row and cells are wider than 2 px).
+    const float4 *pa = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[0] * APAP_HINV_STRIDE);
+    const float4 *pb = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[3] * APAP_HINV_STRIDE);
+    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
+    const float4 b0 = pb[0], b1 = pb[1], b2 = pb[2];
     float4 h0[4], h1[4], h2[4];
+    h0[0] = a0; h1[0] = a1; h2[0] = a2;
+    h0[3] = b0; h1[3] = b1; h2[3] = b2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float4 *hp = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[k] * APAP_HINV_STRIDE);
-        h0[k] = hp[0];
-        h1[k] = hp[1];
-        h2[k] = hp[2];
+    for (int k = 1; k < 3; ++k) {
+        const bool is_a = cell[k] == cell[0];
+        h0[k] = is_a ? a0 : b0;
+        h1[k] = is_a ? a1 : b1;
+        h2[k] = is_a ? a2 : b2;
+        if (!is_a && cell[k] != cell[3]) {  // a third cell inside four pixels: fetch it
+            const float4 *pc = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[k] * APAP_HINV_STRIDE);
+            h0[k] = pc[0];
+            h1[k] = pc[1];
+            h2[k] = pc[2];
+        }
     }
     size_t off[4];
     bool ok[4];
@@ -796,21 +816,32 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
     for (int k = 0; k < 4; ++k) {
         // the dword at the pixel's first byte; for the image's very last pixel read the
         // dword one byte earlier and shift, so that no byte beyond the image is touched
-        const size_t oc = off[k] < last ? off[k] : last;
         unsigned int v;
-        __builtin_memcpy(&v, img + oc, 4);
-        v >>= 8 * (unsigned)(off[k] - oc);
+        if (kGather == 0) {
+            const size_t oc = off[k] < last ? off[k] : last;
+            __builtin_memcpy(&v, img + oc, 4);
+            v >>= 8 * (unsigned)(off[k] - oc);
+        } else if (kGather == 1) {  // two aligned dwords + byte alignment
+            const size_t a0 = off[k] & ~(size_t)3;
+            const size_t lim = (last + 4) & ~(size_t)3;  // first aligned dword that may not be read whole
+            const size_t a1 = a0 + 4 < lim ? a0 + 4 : a0;
+            const unsigned lo = *reinterpret_cast<const unsigned *>(img + (a0 < lim ? a0 : lim - 4));
+            const unsigned hi = *reinterpret_cast<const unsigned *>(img + (a1 < lim ? a1 : lim - 4));
+            v = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(off[k] & 3));
+        } else {
+            v = (unsigned)img[off[k]] | ((unsigned)img[off[k] + 1] << 8) | ((unsigned)img[off[k] + 2] << 16);
+        }
         px[k] = ok[k] ? (v & 0x00ffffffu) : 0u;
     }
-    uint8_t *o = out + g * 3;
-    if (g + 4 <= total) {
+    uint8_t *o = out + (size_t)g * 3;
+    if (g + 4u <= total) {
         Bytes12 v;
         v.a = px[0] | (px[1] << 24);
         v.b = (px[1] >> 8) | (px[2] << 16);
         v.c = (px[2] >> 16) | (px[3] << 8);
         *reinterpret_cast<Bytes12 *>(o) = v;
     } else {
-        for (int k = 0; k < 4 && g + k < total; ++k) {
+        for (unsigned k = 0; k < 4u && g + k < total; ++k) {
             o[3 * k] = (uint8_t)(px[k] & 0xff);
             o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
             o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
@@ -1059,6 +1090,8 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
     if (img_h < 1 || img_w < 1 || (size_t)img_h * img_w < 2)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size (need at least 2 pixels)");
+    if ((unsigned long long)final_w * (unsigned long long)final_h >= (1ull << 31))
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: canvas of 2^31 pixels or more");
     hipStream_t s = (hipStream_t)stream;
     float *hinv_pad;
     int *lut;
@@ -1069,8 +1102,17 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
     const size_t threads = (total + 3) / 4;
     {
         ProfScope prof(APAP_PROF_WARP, s);
-        hipLaunchKernelGGL(k_warp, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_img, img_h, img_w,
-                           hinv_pad, mesh_cols, lut, final_w, final_h, off_x, off_y, d_out);
+        static const int mode = getenv("APAP_WARP_GATHER") ? atoi(getenv("APAP_WARP_GATHER")) : 0;
+        const dim3 grid((unsigned)((threads + 255) / 256));
+        if (mode == 1)
+            hipLaunchKernelGGL(k_warp<1>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
+                               final_h, off_x, off_y, d_out);
+        else if (mode == 2)
+            hipLaunchKernelGGL(k_warp<2>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
+                               final_h, off_x, off_y, d_out);
+        else
+            hipLaunchKernelGGL(k_warp<0>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
+                               final_h, off_x, off_y, d_out);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
