@@ -209,10 +209,16 @@ def main():
         flops = K1_FLOPS_PER_CELL_POINT * res.n * local_cells
         t_k1 = kern["assemble"] * 1e-3
         achieved = flops / t_k1 / 1e12
-        traffic = None
+        resolved = "valu" if a.variant == "valu" else "mfma"      # auto = mfma (apap_kernels.hip plan_solve)
+        # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes
+        # (tools/profile.sh) and committed under profiles/: (2 x FETCH_SIZE + WRITE_SIZE) KiB,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads.
+        traffic, traffic_warp = None, None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(f"{a.config}:{a.variant}:assemble")
+            tj = json.load(open(tfile))
+            traffic = tj.get(f"{a.config}:k_assemble_{resolved}")
+            traffic_warp = tj.get(f"{a.config}:k_warp")
         # K3 (HBM-bound half of the metric): 6 B per in-range pixel, 3 B per blank one
         out_pixels = pair.final_w * pair.final_h
         nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu()) if a.mode == "pairs" or world == 1 else None
@@ -230,15 +236,17 @@ def main():
                      "ms_per_step": t_warp / a.steps * 1e3},
             "solve_ms_per_step": t_solve / a.steps * 1e3,
             "kernels_ms": kern,
-            "roofline": {"kernel": "k_assemble_" + ("mfma" if a.variant == "mfma" else "valu"), "bound": "mfma",
+            "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
-                         "note": "fp64 FMA work: peak is the fp64 matrix = fp64 vector rate; algorithmic "
-                                 "58 flop per (cell, keypoint)"},
+                         "note": "fp64 FMA work: the f64 matrix and vector pipes share one 78.6 TF datasheet "
+                                 "rate (54-59 TF sustained, profiles/r01_peak_fp64.txt); algorithmic 58 flop per "
+                                 "(cell, keypoint) counts sqrt and exp as one flop each, the kernel executes "
+                                 "~128 flop-slots for them (DESIGN.md section 3)"},
             "roofline_warp": None if warp_bytes is None else {
                 "kernel": "k_warp", "bound": "hbm", "achieved": warp_bytes / (kern["warp"] * 1e-3) / 1e9,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (kern["warp"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": None},
+                "traffic": traffic_warp},
         }
         if not a.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows)

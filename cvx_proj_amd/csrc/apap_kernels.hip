@@ -8,7 +8,7 @@
 //                                          keypoint split; SoA so that lanes = cells
 //                                          read and write 512 contiguous bytes
 //   H         [cells][9] f32
-//   Hinv      [cells][12] f32 (padded to 48 B so the warp kernel loads 3 x 16 B)
+//   Hinv      [cells][10] f64 = float32 inverses widened once (80 B: five 16-B loads, no per-pixel cvt)
 //   lut       [final_h + final_w] i32  canvas row -> cell row, canvas column -> cell column
 //
 // Compiled with -ffp-contract=off: every fused multiply-add below is written fma().
@@ -594,7 +594,7 @@ __device__ __forceinline__ bool inv3(const double *m, double *out) {
 // per-cell inverse for the warp (apap.py:201-203): padded float32 copy for the warp
 // kernel, optional dense copy for the caller (the reference's mutated argument).
 __global__ __launch_bounds__(256) void k_invert_cells(const float *__restrict__ H, int cells,
-                                                      float *__restrict__ hinv_pad,
+                                                      double *__restrict__ hinv_pad,
                                                       float *__restrict__ hinv_dense, int *status) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= cells) return;
@@ -602,10 +602,10 @@ __global__ __launch_bounds__(256) void k_invert_cells(const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
     if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
-    float *p = hinv_pad + (size_t)cell * APAP_HINV_STRIDE;
+    double *p = hinv_pad + (size_t)cell * APAP_HINV_STRIDE;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) p[k] = (float)r[k];
-    p[9] = p[10] = p[11] = 0.0f;
+    for (int k = 0; k < 9; ++k) p[k] = (double)(float)r[k];  // the float32 inverse, widened once
+    p[9] = 0.0;
     if (hinv_dense) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (float)r[k];
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_cell_lut(const double *__restrict__ mes
 constexpr int kMaxEdges = 4096;  // per axis; larger meshes take the linear-scan kernel
 
 __global__ __launch_bounds__(256) void k_warp_setup(const float *__restrict__ H, int cells,
-                                                    float *__restrict__ hinv_pad,
+                                                    double *__restrict__ hinv_pad,
                                                     float *__restrict__ hinv_dense, int inv_blocks,
                                                     const double *__restrict__ mesh_w, int n_w,
                                                     const double *__restrict__ mesh_h, int n_h,
@@ -663,10 +663,14 @@ __global__ __launch_bounds__(256) void k_warp_setup(const float *__restrict__ H,
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
         if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
-        float4 *p = reinterpret_cast<float4 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
-        p[0] = make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
-        p[1] = make_float4((float)r[4], (float)r[5], (float)r[6], (float)r[7]);
-        p[2] = make_float4((float)r[8], 0.0f, 0.0f, 0.0f);
+        double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+        // the float32 inverse (what the reference stores, apap.py:203), widened once here
+        // instead of nine v_cvt_f64_f32 per pixel in the warp kernel
+        p[0] = make_double2((double)(float)r[0], (double)(float)r[1]);
+        p[1] = make_double2((double)(float)r[2], (double)(float)r[3]);
+        p[2] = make_double2((double)(float)r[4], (double)(float)r[5]);
+        p[3] = make_double2((double)(float)r[6], (double)(float)r[7]);
+        p[4] = make_double2((double)(float)r[8], 0.0);
         if (hinv_dense) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (float)r[k];
@@ -723,11 +727,28 @@ struct __attribute__((packed, aligned(4))) Bytes12 {
 // one residual correction each - the Markstein sequence, which returns the correctly
 // rounded quotient the reference's true division produces (checked against the oracle's
 // coordinates in tests: equal).
-__device__ __forceinline__ void target_from(const float4 r0, const float4 r1, const float4 r2, double x,
-                                            double y, double &tx, double &ty) {
-    const double t0 = fma((double)r0.z, 1.0, fma((double)r0.y, y, (double)r0.x * x));
-    const double t1 = fma((double)r1.y, 1.0, fma((double)r1.x, y, (double)r0.w * x));
-    const double t2 = fma((double)r2.x, 1.0, fma((double)r1.w, y, (double)r1.z * x));
+struct Hinv9 {
+    double2 a, b, c, d, e;  // h0 h1 | h2 h3 | h4 h5 | h6 h7 | h8 -
+};
+
+__device__ __forceinline__ Hinv9 load_hinv(const double *__restrict__ hinv_pad, unsigned cell) {
+    const double2 *p = reinterpret_cast<const double2 *>(hinv_pad) + cell * (APAP_HINV_STRIDE / 2);
+    Hinv9 h;
+    h.a = p[0]; h.b = p[1]; h.c = p[2]; h.d = p[3]; h.e = p[4];
+    return h;
+}
+
+__device__ __forceinline__ Hinv9 select_hinv(bool first, const Hinv9 &x, const Hinv9 &y) {
+    Hinv9 h;
+    h.a = first ? x.a : y.a; h.b = first ? x.b : y.b; h.c = first ? x.c : y.c;
+    h.d = first ? x.d : y.d; h.e.x = first ? x.e.x : y.e.x; h.e.y = 0.0;
+    return h;
+}
+
+__device__ __forceinline__ void target_from(const Hinv9 &h, double x, double y, double &tx, double &ty) {
+    const double t0 = fma(h.b.x, 1.0, fma(h.a.y, y, h.a.x * x));
+    const double t1 = fma(h.c.y, 1.0, fma(h.c.x, y, h.b.y * x));
+    const double t2 = fma(h.e.x, 1.0, fma(h.d.y, y, h.d.x * x));
     double r = __builtin_amdgcn_rcp(t2);
     r = fma(fma(-t2, r, 1.0), r, r);
     r = fma(fma(-t2, r, 1.0), r, r);
@@ -736,10 +757,9 @@ __device__ __forceinline__ void target_from(const float4 r0, const float4 r1, co
     ty = fma(fma(-t2, q1, t1), r, q1);
 }
 
-__device__ __forceinline__ void target_of(const float *__restrict__ hinv_pad, int cell, double x,
+__device__ __forceinline__ void target_of(const double *__restrict__ hinv_pad, int cell, double x,
                                           double y, double &tx, double &ty) {
-    const float4 *hp = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
-    target_from(hp[0], hp[1], hp[2], x, y, tx, ty);
+    target_from(load_hinv(hinv_pad, (unsigned)cell), x, y, tx, ty);
 }
 
 // K3: backward warp.  One thread = 4 consecutive canvas pixels in flat order = 12
@@ -752,13 +772,13 @@ __device__ __forceinline__ void target_of(const float *__restrict__ hinv_pad, in
 // issue-bound.  Requires img_bytes >= 4.
 template <int kGather>
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, int img_h, int img_w,
-                                              const float *__restrict__ hinv_pad, int mesh_cols,
+                                              const double *__restrict__ hinv_pad, int mesh_cols,
                                               const int *__restrict__ lut, int final_w, int final_h,
                                               int off_x, int off_y, uint8_t *__restrict__ out) {
     // 32-bit pixel indices (the launcher refuses canvases of 2^31 pixels or more): a
     // 64-bit division here expands into ~100 instructions with branches
     const unsigned total = (unsigned)final_w * (unsigned)final_h;
-    const size_t last = (size_t)img_h * img_w * 3 - 4;
+    const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
     const unsigned g = (blockIdx.x * 256u + threadIdx.x) * 4u;
     if (g >= total) return;
     int ii[4], jj[4];
@@ -780,36 +800,25 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
     for (int k = 0; k < 4; ++k) cell[k] = (ii[k] == ii[0] ? r0 : r3) * mesh_cols + lut[final_h + jj[k]];
     // H^-1 of the first and the last pixel's cells; the two in between almost always sit in
     // one of those (cell indices are monotone along a row and cells are wider than 2 px).
-    const float4 *pa = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[0] * APAP_HINV_STRIDE);
-    const float4 *pb = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[3] * APAP_HINV_STRIDE);
-    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2];
-    const float4 b0 = pb[0], b1 = pb[1], b2 = pb[2];
-    float4 h0[4], h1[4], h2[4];
-    h0[0] = a0; h1[0] = a1; h2[0] = a2;
-    h0[3] = b0; h1[3] = b1; h2[3] = b2;
+    Hinv9 hv[4];
+    hv[0] = load_hinv(hinv_pad, (unsigned)cell[0]);
+    hv[3] = load_hinv(hinv_pad, (unsigned)cell[3]);
 #pragma unroll
     for (int k = 1; k < 3; ++k) {
         const bool is_a = cell[k] == cell[0];
-        h0[k] = is_a ? a0 : b0;
-        h1[k] = is_a ? a1 : b1;
-        h2[k] = is_a ? a2 : b2;
-        if (!is_a && cell[k] != cell[3]) {  // a third cell inside four pixels: fetch it
-            const float4 *pc = reinterpret_cast<const float4 *>(hinv_pad + (size_t)cell[k] * APAP_HINV_STRIDE);
-            h0[k] = pc[0];
-            h1[k] = pc[1];
-            h2[k] = pc[2];
-        }
+        hv[k] = select_hinv(is_a, hv[0], hv[3]);
+        if (!is_a && cell[k] != cell[3]) hv[k] = load_hinv(hinv_pad, (unsigned)cell[k]);  // a third cell inside four pixels
     }
-    size_t off[4];
+    unsigned off[4];  // byte offsets into the image: the launcher refuses images of 4 GiB or more
     bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         double tx, ty;
-        target_from(h0[k], h1[k], h2[k], (double)(jj[k] - off_x), (double)(ii[k] - off_y), tx, ty);
+        target_from(hv[k], (double)(jj[k] - off_x), (double)(ii[k] - off_y), tx, ty);
         // strict inequalities and truncation, apap.py:214-215; NaN fails every comparison
         ok[k] = 0.0 < tx && tx < (double)img_w && 0.0 < ty && ty < (double)img_h;
         const int ix = ok[k] ? (int)tx : 0, iy = ok[k] ? (int)ty : 0;
-        off[k] = ((size_t)iy * img_w + ix) * 3;
+        off[k] = ((unsigned)iy * (unsigned)img_w + (unsigned)ix) * 3u;
     }
     unsigned int px[4];
 #pragma unroll
@@ -818,13 +827,13 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
         // dword one byte earlier and shift, so that no byte beyond the image is touched
         unsigned int v;
         if (kGather == 0) {
-            const size_t oc = off[k] < last ? off[k] : last;
+            const unsigned oc = off[k] < last ? off[k] : last;
             __builtin_memcpy(&v, img + oc, 4);
-            v >>= 8 * (unsigned)(off[k] - oc);
+            v >>= 8 * (off[k] - oc);
         } else if (kGather == 1) {  // two aligned dwords + byte alignment
-            const size_t a0 = off[k] & ~(size_t)3;
-            const size_t lim = (last + 4) & ~(size_t)3;  // first aligned dword that may not be read whole
-            const size_t a1 = a0 + 4 < lim ? a0 + 4 : a0;
+            const unsigned a0 = off[k] & ~3u;
+            const unsigned lim = (last + 4u) & ~3u;  // first aligned dword that may not be read whole
+            const unsigned a1 = a0 + 4 < lim ? a0 + 4 : a0;
             const unsigned lo = *reinterpret_cast<const unsigned *>(img + (a0 < lim ? a0 : lim - 4));
             const unsigned hi = *reinterpret_cast<const unsigned *>(img + (a1 < lim ? a1 : lim - 4));
             v = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(off[k] & 3));
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
 }
 
 // coordinates only (parity tests of the arithmetic of k_warp)
-__global__ __launch_bounds__(256) void k_warp_coords(const float *__restrict__ hinv_pad, int mesh_cols,
+__global__ __launch_bounds__(256) void k_warp_coords(const double *__restrict__ hinv_pad, int mesh_cols,
                                                      const int *__restrict__ lut, int final_w,
                                                      int final_h, int off_x, int off_y,
                                                      double *__restrict__ coords) {
@@ -1040,7 +1049,7 @@ int apap_weights_device(const double *d_table, int n, const double *d_vertices, 
 
 size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h) {
     if (mesh_rows < 1 || mesh_cols < 1 || final_w < 1 || final_h < 1) return 0;
-    const size_t hinv = (size_t)mesh_rows * mesh_cols * APAP_HINV_STRIDE * sizeof(float);
+    const size_t hinv = (size_t)mesh_rows * mesh_cols * APAP_HINV_STRIDE * sizeof(double);
     const size_t lut = ((size_t)final_w + final_h) * sizeof(int);
     return ((hinv + 255) / 256) * 256 + ((lut + 255) / 256) * 256;
 }
@@ -1048,7 +1057,7 @@ size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int 
 static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
                          int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
                          float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                         hipStream_t s, float **hinv_pad, int **lut) {
+                         hipStream_t s, double **hinv_pad, int **lut) {
     if (!d_Hfwd || !d_mesh_w || !d_mesh_h || !d_work || !d_status)
         return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
     if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
@@ -1056,8 +1065,8 @@ static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, cons
     const size_t need = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
     if (work_bytes < need) return apap::fail(APAP_ERR_WORKSPACE, "warp: workspace %zu < %zu bytes", work_bytes, need);
     const int cells = mesh_rows * mesh_cols;
-    const size_t hinv_bytes = (((size_t)cells * APAP_HINV_STRIDE * sizeof(float) + 255) / 256) * 256;
-    *hinv_pad = (float *)d_work;
+    const size_t hinv_bytes = (((size_t)cells * APAP_HINV_STRIDE * sizeof(double) + 255) / 256) * 256;
+    *hinv_pad = (double *)d_work;
     *lut = (int *)((char *)d_work + hinv_bytes);
     if (n_w <= kMaxEdges && n_h <= kMaxEdges) {
         // one launch: cell inverses + lookup table (reported under the INVERT slot)
@@ -1090,10 +1099,12 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
     if (img_h < 1 || img_w < 1 || (size_t)img_h * img_w < 2)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size (need at least 2 pixels)");
+    if ((unsigned long long)img_h * (unsigned long long)img_w * 3ull >= (1ull << 32))
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: image of 4 GiB or more");
     if ((unsigned long long)final_w * (unsigned long long)final_h >= (1ull << 31))
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: canvas of 2^31 pixels or more");
     hipStream_t s = (hipStream_t)stream;
-    float *hinv_pad;
+    double *hinv_pad;
     int *lut;
     const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
                                  d_Hinv_out, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
@@ -1125,7 +1136,7 @@ int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, c
                             int *d_status, void *stream) {
     if (!d_coords) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_coords_device: null output");
     hipStream_t s = (hipStream_t)stream;
-    float *hinv_pad;
+    double *hinv_pad;
     int *lut;
     const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
                                  nullptr, d_work, work_bytes, d_status, s, &hinv_pad, &lut);

@@ -47,8 +47,8 @@ extern "C" {
 #define APAP_TABLE_STRIDE 32
 /* Doubles in the de-normalisation block: inv(C2), C1, inv(N2), N1 (3x3 row-major each). */
 #define APAP_DENORM_DOUBLES 36
-/* Floats per cell in the padded inverse-homography buffer the warp kernel reads. */
-#define APAP_HINV_STRIDE 12
+/* Doubles per cell in the padded inverse-homography buffer the warp kernel reads. */
+#define APAP_HINV_STRIDE 10
 
 /* Solver variants (apap_set_solver_variant).  Both produce the same numbers up to
  * the summation order of the 30 moment sums. */

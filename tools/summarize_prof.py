@@ -12,7 +12,7 @@ out = sys.argv[1]
 
 def short(name):
     for k in ("k_assemble_valu", "k_assemble_mfma", "k_eigen_denorm", "k_invert_cells", "k_cell_lut", "k_warp_coords",
-              "k_warp", "k_flatten", "k_weights", "k_blend"):
+              "k_warp_setup", "k_warp", "k_flatten", "k_weights", "k_blend"):
         if k in name:
             return k
     return None
