@@ -91,6 +91,20 @@ class Resident:
                                          self.out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
                                          self.status.data_ptr(), ctypes.c_void_p(stream)))
 
+    def stitch(self, stream):
+        """Fused warp + paste + uniform_blend (the reference's commented-out tail,
+        apap.py:258-262); timed as an extra, not part of ``value``."""
+        p = self.pair
+        if not hasattr(self, "center"):
+            g = torch.Generator(device="cpu").manual_seed(1)
+            self.center = torch.randint(0, 256, p.shape, dtype=torch.uint8, generator=g).to(self.img.device)
+        N.check(N.lib().apap_stitch_device(self.img.data_ptr(), p.shape[0], p.shape[1], self.center.data_ptr(),
+                                           p.shape[0], p.shape[1], self.H.data_ptr(), self.rows, self.cols,
+                                           self.mesh_w.data_ptr(), p.mesh.shape[1], self.mesh_h.data_ptr(),
+                                           p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
+                                           self.out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
+                                           self.status.data_ptr(), ctypes.c_void_p(stream)))
+
 
 def cpu_baseline(cfg, budget_cells, budget_rows):
     """The oracle's faithful-loop port on this host: a bounded, seeded sample of the
@@ -191,6 +205,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_solve, t_warp = (float(v) for v in tt.cpu())
     assert int(res.status.cpu()[0]) == 0, "device status word set during the timed region"
+    t_stitch = None
+    if hasattr(res, "stitch"):      # extra: the fused stitch, same canvas, not part of `value`
+        res.stitch(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            res.stitch(stream)
+        torch.cuda.synchronize()
+        t_stitch = time.perf_counter() - t0
+        res.warp(stream)            # leave the plain warped canvas in res.out for the byte count below
+        torch.cuda.synchronize()
 
     # per-kernel durations, HIP events on the launch stream (rank-local)
     N.lib().apap_profile_enable(1)
@@ -235,6 +260,10 @@ def main():
             "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
                      "ms_per_step": t_warp / a.steps * 1e3},
             "solve_ms_per_step": t_solve / a.steps * 1e3,
+            "stitch": None if t_stitch is None else {
+                "value": pair.final_w * pair.final_h * a.steps / t_stitch / 1e6, "unit": "Mpix/s (rank 0)",
+                "ms_per_step": t_stitch / a.steps * 1e3,
+                "note": "fused warp + paste + uniform_blend, apap.py:258-262; extra, not in `value`"},
             "kernels_ms": kern,
             "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",

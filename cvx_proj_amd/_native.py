@@ -55,6 +55,8 @@ SIGNATURES = {
                                         C.c_double, _f32p, _f64p, C.c_int]),
     "apap_local_warp": (C.c_int, [_u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
+    "apap_local_stitch": (C.c_int, [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p,
+                                    C.c_int, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
     "apap_warp_coords": (C.c_int, [_f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, _f64p, C.c_int]),
     "apap_invert_normalize_flatten": (C.c_int, [_f32p, C.c_int, _f64p, C.c_int]),
@@ -66,6 +68,8 @@ SIGNATURES = {
     "apap_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apap_warp_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "apap_stitch_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
+                                     _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "apap_warp_coords_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp]),
     "apap_flatten_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
@@ -199,6 +203,26 @@ def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inve
                                 _ptr(mesh_w, C.c_double), mesh_w.size, _ptr(mesh_h, C.c_double), mesh_h.size,
                                 int(final_w), int(final_h), int(off_x), int(off_y), _ptr(out, C.c_uint8),
                                 _ptr(Hinv, C.c_float), device))
+    return out, Hinv
+
+
+def local_stitch(img, center, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=False, device=-1):
+    """Fused local_warp + paste of ``center`` at the offsets + uniform_blend."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    center = np.ascontiguousarray(center, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3 or center.ndim != 3 or center.shape[2] != 3:
+        raise ValueError(f"images must be (h, w, 3); got {img.shape} and {center.shape}")
+    H = as_f32(H, (3, 3))
+    rows, cols = H.shape[:2]
+    mesh_w = np.ascontiguousarray(mesh_w, dtype=np.float64)
+    mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
+    out = np.empty((final_h, final_w, 3), np.uint8)
+    Hinv = np.empty_like(H) if want_inverse else None
+    check(lib().apap_local_stitch(_ptr(img, C.c_uint8), img.shape[0], img.shape[1], _ptr(center, C.c_uint8),
+                                  center.shape[0], center.shape[1], _ptr(H, C.c_float), rows, cols,
+                                  _ptr(mesh_w, C.c_double), mesh_w.size, _ptr(mesh_h, C.c_double), mesh_h.size,
+                                  int(final_w), int(final_h), int(off_x), int(off_y), _ptr(out, C.c_uint8),
+                                  _ptr(Hinv, C.c_float), device))
     return out, Hinv
 
 

@@ -12,7 +12,7 @@ the inputs come from ``--pair``)::
 
     python -m cvx_proj_amd.apap [case_idx] [img_idx] [--pair pair.npz | --synth C1]
                                 [--config configs/case1.txt] [--out-prefix ../diff_1/results/]
-                                [--mesh-size 100] [--gamma 0.5] [--sigma 100] [--warp out.npy]
+                                [--mesh-size 100] [--gamma 0.5] [--sigma 100] [--warp out.npy | --stitch out.npy]
 """
 from __future__ import annotations
 
@@ -119,6 +119,17 @@ class APAP:
         return warped
 
 
+    def local_stitch(self, ori_img, center_img, local_homography, mesh):
+        """The blend the reference's ``__main__`` keeps commented out (apap.py:258-262) as
+        one fused pass: ``uniform_blend(local_warp(ori_img, H, mesh), paste(center_img))``
+        with the centre image pasted at ``(offset_x, offset_y)``.  Does not mutate
+        ``local_homography``."""
+        mesh_w, mesh_h = mesh
+        out, _ = _native.local_stitch(ori_img, center_img, local_homography, mesh_w, mesh_h, self.final_width,
+                                      self.final_height, self.offset_x, self.offset_y, device=self.device)
+        return out
+
+
 # ------------------------------------------------------------------------------------
 # CLI: apap.py:220-265
 # ------------------------------------------------------------------------------------
@@ -143,9 +154,11 @@ def read_config(path):
 
 
 def run_pair(src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
-             other_img=None, device=-1):
+             other_img=None, center_img=None, device=-1):
     """Body of the reference's ``__main__`` between loading and saving
-    (apap.py:238-264).  Returns ``(H_flat (m*m, 9) float64, warped or None)``."""
+    (apap.py:238-264).  Returns ``(H_flat (m*m, 9) float64, canvas or None)``; the canvas
+    is the warped other image, or - when ``center_img`` is given - the blended stitch
+    of apap.py:258-262."""
 
     class _S:
         def __init__(self, shape):
@@ -156,7 +169,10 @@ def run_pair(src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma
     vertices = get_vertice((fw, fh), mesh_size, (ox, oy))
     eng = APAP(gamma, sigma, [fw, fh], [ox, oy], device=device)
     H, _ = eng.local_homography(src, dst, vertices, return_weights=False)
-    warped = eng.local_warp(other_img, H.copy(), mesh) if other_img is not None else None
+    if other_img is not None and center_img is not None:
+        warped = eng.local_stitch(other_img, center_img, H, mesh)
+    else:
+        warped = eng.local_warp(other_img, H.copy(), mesh) if other_img is not None else None
     flat = _native.invert_normalize_flatten(H, device=device)   # apap.py:250-264
     return flat, warped
 
@@ -174,6 +190,8 @@ def main(argv=None):
     ap.add_argument("--sigma", type=float)
     ap.add_argument("--out-prefix", default="../diff_1/results/")
     ap.add_argument("--warp", help="also run local_warp and save the canvas to this .npy")
+    ap.add_argument("--stitch", help="run the fused warp + blend with the centre image (the reference's "
+                                     "commented-out tail, apap.py:258-262) and save the canvas to this .npy")
     ap.add_argument("--device", type=int, default=-1)
     a = ap.parse_args(argv)
 
@@ -192,25 +210,27 @@ def main(argv=None):
         z = np.load(a.pair)
         src, dst, Hg = z["src"], z["dst"], z["H"]
         other_shape, center_shape = tuple(z["other_shape"]), tuple(z["center_shape"])
-        other_img = z["other_img"] if (a.warp and "other_img" in z) else None
+        other_img = z["other_img"] if ((a.warp or a.stitch) and "other_img" in z) else None
+        center_img = z["center_img"] if (a.stitch and "center_img" in z) else None
     elif a.synth:
         from .synth import CONFIGS, synth_pair
         w, h, n, m, seed = CONFIGS[a.synth]
         if a.mesh_size is None and not a.config:
             par["mesh_size"] = m
-        p = synth_pair(w, h, n, par["mesh_size"], seed, with_image=bool(a.warp))
+        p = synth_pair(w, h, n, par["mesh_size"], seed, with_image=bool(a.warp or a.stitch))
         src, dst, Hg, other_shape, center_shape, other_img = p.src, p.dst, p.Hg, p.shape, p.shape, p.img
+        center_img = (np.random.default_rng(seed + 1).integers(0, 256, p.shape, dtype=np.uint8) if a.stitch else None)
     else:
         ap.error("the reference's dataset (../diff_1) is not distributed: give --pair or --synth")
 
     flat, warped = run_pair(src, dst, Hg, other_shape, center_shape, par["mesh_size"], par["gamma"], par["sigma"],
-                            other_img=other_img, device=a.device)
+                            other_img=other_img, center_img=center_img, device=a.device)
     print(f"local_homography shape: {(par['mesh_size'], par['mesh_size'], 3, 3)}")
     out_dir = f"{a.out_prefix}case{a.case_idx}"
     os.makedirs(out_dir, exist_ok=True)
     save2mat(f"case{a.case_idx}/H3{a.img_idx}_apap", flat, name="H", prefix=a.out_prefix)
-    if a.warp and warped is not None:
-        np.save(a.warp, warped)
+    if (a.warp or a.stitch) and warped is not None:
+        np.save(a.stitch or a.warp, warped)
     return 0
 
 

@@ -164,7 +164,8 @@ int apap_local_homography(const float *src, const float *dst, int n, const doubl
     return APAP_OK;
 }
 
-static int warp_common(const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
+static int warp_common(const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
+                       int center_w, const float *Hfwd, int mesh_rows,
                        int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
                        int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
                        double *coords, int device, const char *who) {
@@ -201,9 +202,20 @@ static int warp_common(const uint8_t *img, int img_h, int img_w, const float *Hf
         if ((rc = slot_get(S_IMG, img_bytes, dev, &d_img))) return rc;
         if ((rc = slot_get(S_OUT, pixels * 3, dev, &d_out))) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(d_img, img, img_bytes, hipMemcpyHostToDevice, nullptr));
-        rc = apap_warp_device((const uint8_t *)d_img, img_h, img_w, (const float *)d_H, mesh_rows, mesh_cols,
-                              (const double *)d_mw, n_w, (const double *)d_mh, n_h, final_w, final_h, off_x, off_y,
-                              (uint8_t *)d_out, (float *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
+        if (center) {
+            void *d_center;
+            const size_t cbytes = (size_t)center_h * center_w * 3;
+            if ((rc = slot_get(S_AUX, cbytes, dev, &d_center))) return rc;
+            APAP_HIP_TRY(hipMemcpyAsync(d_center, center, cbytes, hipMemcpyHostToDevice, nullptr));
+            rc = apap_stitch_device((const uint8_t *)d_img, img_h, img_w, (const uint8_t *)d_center, center_h, center_w,
+                                    (const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w,
+                                    (const double *)d_mh, n_h, final_w, final_h, off_x, off_y, (uint8_t *)d_out,
+                                    (float *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
+        } else {
+            rc = apap_warp_device((const uint8_t *)d_img, img_h, img_w, (const float *)d_H, mesh_rows, mesh_cols,
+                                  (const double *)d_mw, n_w, (const double *)d_mh, n_h, final_w, final_h, off_x, off_y,
+                                  (uint8_t *)d_out, (float *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
+        }
         if (rc) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(out, d_out, pixels * 3, hipMemcpyDeviceToHost, nullptr));
         if (Hinv_out)
@@ -221,16 +233,27 @@ int apap_local_warp(const uint8_t *img, int img_h, int img_w, const float *Hfwd,
                     int device) {
     if (!img || !out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp: null image");
     if (img_h < 1 || img_w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp: bad image size");
-    return warp_common(img, img_h, img_w, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h,
-                       off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_warp");
+    return warp_common(img, img_h, img_w, nullptr, 0, 0, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w,
+                       final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_warp");
+}
+
+int apap_local_stitch(const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
+                      int center_w, const float *Hfwd, int mesh_rows, int mesh_cols,
+                      const double *mesh_w, int n_w, const double *mesh_h, int n_h, int final_w,
+                      int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out, int device) {
+    if (!img || !out || !center) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_stitch: null image");
+    if (img_h < 1 || img_w < 1 || center_h < 1 || center_w < 1)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_stitch: bad image size");
+    return warp_common(img, img_h, img_w, center, center_h, center_w, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h,
+                       n_h, final_w, final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_stitch");
 }
 
 int apap_warp_coords(const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
                      const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
                      double *coords, int device) {
     if (!coords) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_coords: null output");
-    return warp_common(nullptr, 0, 0, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h, off_x,
-                       off_y, nullptr, nullptr, coords, device, "apap_warp_coords");
+    return warp_common(nullptr, 0, 0, nullptr, 0, 0, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w,
+                       final_h, off_x, off_y, nullptr, nullptr, coords, device, "apap_warp_coords");
 }
 
 int apap_invert_normalize_flatten(const float *H, int cells, double *out, int device) {

@@ -770,11 +770,15 @@ __device__ __forceinline__ void target_of(const double *__restrict__ hinv_pad, i
 // then arithmetic, then all gathers) so that a thread keeps 8 / 12 / 4 loads in flight
 // instead of walking a dependent chain per pixel: the kernel is latency-bound, not
 // issue-bound.  Requires img_bytes >= 4.
-template <int kGather>
+// kBlend fuses the stitch the reference's __main__ has commented out (apap.py:258-262):
+// paste the centre image at (off_x, off_y), then uniform_blend (apap_utils.py:75-88) - in
+// the same pass, so the warped canvas is never written and re-read.
+template <bool kBlend>
 __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, int img_h, int img_w,
                                               const double *__restrict__ hinv_pad, int mesh_cols,
                                               const int *__restrict__ lut, int final_w, int final_h,
-                                              int off_x, int off_y, uint8_t *__restrict__ out) {
+                                              int off_x, int off_y, uint8_t *__restrict__ out,
+                                              const uint8_t *__restrict__ center, int center_h, int center_w) {
     // 32-bit pixel indices (the launcher refuses canvases of 2^31 pixels or more): a
     // 64-bit division here expands into ~100 instructions with branches
     const unsigned total = (unsigned)final_w * (unsigned)final_h;
@@ -826,21 +830,29 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
         // the dword at the pixel's first byte; for the image's very last pixel read the
         // dword one byte earlier and shift, so that no byte beyond the image is touched
         unsigned int v;
-        if (kGather == 0) {
-            const unsigned oc = off[k] < last ? off[k] : last;
-            __builtin_memcpy(&v, img + oc, 4);
-            v >>= 8 * (off[k] - oc);
-        } else if (kGather == 1) {  // two aligned dwords + byte alignment
-            const unsigned a0 = off[k] & ~3u;
-            const unsigned lim = (last + 4u) & ~3u;  // first aligned dword that may not be read whole
-            const unsigned a1 = a0 + 4 < lim ? a0 + 4 : a0;
-            const unsigned lo = *reinterpret_cast<const unsigned *>(img + (a0 < lim ? a0 : lim - 4));
-            const unsigned hi = *reinterpret_cast<const unsigned *>(img + (a1 < lim ? a1 : lim - 4));
-            v = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(off[k] & 3));
-        } else {
-            v = (unsigned)img[off[k]] | ((unsigned)img[off[k] + 1] << 8) | ((unsigned)img[off[k] + 2] << 16);
-        }
+        const unsigned oc = off[k] < last ? off[k] : last;
+        __builtin_memcpy(&v, img + oc, 4);
+        v >>= 8 * (off[k] - oc);
         px[k] = ok[k] ? (v & 0x00ffffffu) : 0u;
+    }
+    if (kBlend) {
+        const unsigned clast = (unsigned)center_h * (unsigned)center_w * 3u - 4u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ci = ii[k] - off_y, cj = jj[k] - off_x;
+            const bool in = ci >= 0 && ci < center_h && cj >= 0 && cj < center_w;
+            const unsigned co = in ? ((unsigned)ci * (unsigned)center_w + (unsigned)cj) * 3u : 0u;
+            const unsigned cc = co < clast ? co : clast;
+            unsigned int c;
+            __builtin_memcpy(&c, center + cc, 4);
+            c = in ? ((c >> (8 * (co - cc))) & 0x00ffffffu) : 0u;
+            // uniform_blend: a pixel is "present" when its channel mean is > 0, i.e. any
+            // channel is non-zero; both present -> floor((a + b) / 2) per channel (float64
+            // sum * 0.5, astype(uint8)), otherwise a + b with one of them 0
+            const unsigned w = px[k];
+            const unsigned avg = (w & c) + (((w ^ c) & 0x00fefefeu) >> 1);
+            px[k] = (w != 0u && c != 0u) ? avg : (w | c);
+        }
     }
     uint8_t *o = out + (size_t)g * 3;
     if (g + 4u <= total) {
@@ -1091,12 +1103,23 @@ static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, cons
     return APAP_OK;
 }
 
-int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
+                     int center_w, const float *d_Hfwd, int mesh_rows,
                      int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream) {
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
+    if (d_center) {
+        // the reference pastes with a numpy slice assignment, which raises when the
+        // centre image does not fit the canvas at the offsets
+        if (center_h < 1 || center_w < 1 || (size_t)center_h * center_w < 2 || off_x < 0 || off_y < 0 ||
+            (long long)off_y + center_h > final_h || (long long)off_x + center_w > final_w)
+            return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: centre image %dx%d at (%d,%d) does not fit canvas %dx%d",
+                              center_w, center_h, off_x, off_y, final_w, final_h);
+        if ((unsigned long long)center_h * (unsigned long long)center_w * 3ull >= (1ull << 32))
+            return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: centre image of 4 GiB or more");
+    }
     if (img_h < 1 || img_w < 1 || (size_t)img_h * img_w < 2)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size (need at least 2 pixels)");
     if ((unsigned long long)img_h * (unsigned long long)img_w * 3ull >= (1ull << 32))
@@ -1113,21 +1136,37 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
     const size_t threads = (total + 3) / 4;
     {
         ProfScope prof(APAP_PROF_WARP, s);
-        static const int mode = getenv("APAP_WARP_GATHER") ? atoi(getenv("APAP_WARP_GATHER")) : 0;
         const dim3 grid((unsigned)((threads + 255) / 256));
-        if (mode == 1)
-            hipLaunchKernelGGL(k_warp<1>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out);
-        else if (mode == 2)
-            hipLaunchKernelGGL(k_warp<2>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out);
+        if (d_center)
+            hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
+                               final_h, off_x, off_y, d_out, d_center, center_h, center_w);
         else
-            hipLaunchKernelGGL(k_warp<0>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out);
+            hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
+                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
     return APAP_OK;
+}
+
+int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+                     int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
+                     int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
+                     float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
+                     void *stream) {
+    return warp_impl(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
+                     final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream);
+}
+
+int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
+                       int center_w, const float *d_Hfwd, int mesh_rows, int mesh_cols,
+                       const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
+                       int final_h, int off_x, int off_y, uint8_t *d_out, float *d_Hinv_out, void *d_work,
+                       size_t work_bytes, int *d_status, void *stream) {
+    if (!d_center) return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: null centre image");
+    return warp_impl(d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
+                     d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status,
+                     stream);
 }
 
 int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,

@@ -140,6 +140,16 @@ int apap_local_warp(const uint8_t *img, int img_h, int img_w, const float *Hfwd,
                     int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
                     int device);
 
+/* The stitch the reference's __main__ keeps commented out (apap.py:258-262), fused into
+ * one pass: warp `img` like apap_local_warp, paste `center` (center_h x center_w x 3) at
+ * (off_x, off_y) on an empty canvas, uniform_blend (apap_utils.py:75-88) the two.  The
+ * centre image must fit the canvas at the offsets (the reference's slice assignment raises
+ * otherwise): APAP_ERR_INVALID_ARG. */
+int apap_local_stitch(const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
+                      int center_w, const float *Hfwd, int mesh_rows, int mesh_cols,
+                      const double *mesh_w, int n_w, const double *mesh_h, int n_h, int final_w,
+                      int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out, int device);
+
 /* Same inputs as apap_local_warp; writes the float64 target coordinates (tx, ty) of
  * every canvas pixel (apap.py:211-213) instead of gathering.  coords: final_h x
  * final_w x 2 float64.  For parity tests of the coordinate arithmetic. */
@@ -184,6 +194,13 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream);
+
+/* Resident-data twin of apap_local_stitch. */
+int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
+                       int center_w, const float *d_Hfwd, int mesh_rows, int mesh_cols,
+                       const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
+                       int final_h, int off_x, int off_y, uint8_t *d_out, float *d_Hinv_out, void *d_work,
+                       size_t work_bytes, int *d_status, void *stream);
 
 /* Coordinates-only twin of apap_warp_device (d_coords: final_h x final_w x 2 doubles). */
 int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,

@@ -39,7 +39,7 @@ __all__ = [
     "normalize_2d_pts", "conditioner_from_pts", "point_normalize", "dlt_rows",
     "prepare", "cell_weights", "local_homography_loop", "local_homography_fast",
     "invert_cells_f32", "cell_lookup", "local_warp_loop", "local_warp_fast",
-    "warp_coords_fast", "invert_normalize_flatten", "project", "reprojection_rmse_delta",
+    "warp_coords_fast", "stitch", "invert_normalize_flatten", "project", "reprojection_rmse_delta",
 ]
 
 
@@ -356,6 +356,16 @@ def local_warp_fast(ori_img, hinv, mesh, final_wh, offset, band=256):
         px[~ok] = 0
         warped[lo:hi] = px
     return warped
+
+
+def stitch(warped, center_img, offset):
+    """The commented-out tail of the reference's __main__ (apap.py:259-261): paste the
+    centre image on an empty canvas at the offsets, then uniform_blend."""
+    off_x, off_y = offset
+    ch, cw = center_img.shape[:2]
+    dst_temp = np.zeros_like(warped)
+    dst_temp[off_y:ch + off_y, off_x:cw + off_x, :] = center_img
+    return uniform_blend(warped, dst_temp)
 
 
 # --------------------------------------------------------------------------------------

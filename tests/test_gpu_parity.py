@@ -357,3 +357,45 @@ def test_sharded_solver_single_rank_equals_direct(native):
     H = s.solve().cpu().numpy().reshape(100, 100, 3, 3)
     H_direct, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
     assert np.array_equal(H, H_direct)
+
+
+# ------------------------------------------------------------------ fused stitch (apap.py:258-262)
+@pytest.mark.parametrize("name", TINY)
+def test_stitch_vs_reference_pieces(native, golden, name):
+    """warp + paste + uniform_blend in one kernel equals the composition of the reference's
+    own pieces (its warped canvas, numpy paste, its uniform_blend)."""
+    g = golden(name)
+    fw, fh, ox, oy = (int(v) for v in g["final"])
+    rng = np.random.default_rng(4)
+    center = rng.integers(0, 256, g["img"].shape, dtype=np.uint8)
+    center[rng.random(center.shape[:2]) < 0.2] = 0             # black holes: the non-overlap branch
+    ref = O.stitch(g["warped_ref"], center, (ox, oy))
+    out, _ = native.local_stitch(g["img"], center, g["H_ref"], g["mesh"][0], g["mesh"][1], fw, fh, ox, oy)
+    assert np.array_equal(out, ref)
+    eng = APAP(float(g["gamma"]), float(g["sigma"]), [fw, fh], [ox, oy])
+    H = g["H_ref"].copy()
+    assert np.array_equal(eng.local_stitch(g["img"], center, H, g["mesh"]), ref)
+    assert np.array_equal(H, g["H_ref"])                        # not mutated
+
+
+def test_stitch_full_size_c3(native, golden):
+    p = config_pair("C3")
+    rng = np.random.default_rng(6)
+    center = rng.integers(0, 256, p.shape, dtype=np.uint8)
+    H = golden("c3_ref")["H_ref"]
+    warped, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    ref = O.stitch(warped, center, (p.off_x, p.off_y))
+    out, _ = native.local_stitch(p.img, center, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    assert np.array_equal(out, ref)
+    # the separate blend entry point gives the same canvas
+    pasted = np.zeros_like(warped)
+    pasted[p.off_y:p.off_y + p.shape[0], p.off_x:p.off_x + p.shape[1]] = center
+    assert np.array_equal(native.uniform_blend(warped, pasted), ref)
+
+
+def test_stitch_centre_must_fit_canvas(native):
+    img = np.zeros((16, 16, 3), np.uint8)
+    H = np.tile(np.eye(3, dtype=np.float32), (2, 2, 1, 1))
+    with pytest.raises(native.ApapError) as e:
+        native.local_stitch(img, np.zeros((16, 16, 3), np.uint8), H, [0.0, 8.0, 16.0], [0.0, 8.0, 16.0], 16, 16, 1, 0)
+    assert e.value.code == native.ERR_INVALID_ARG
