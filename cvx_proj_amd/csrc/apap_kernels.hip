@@ -101,6 +101,62 @@ __device__ __forceinline__ double cell_weight_sq(double vx, double vy, double sx
     return fmax(exp_nonpos(-(g * inv_sigma2)), gamma2);
 }
 
+// Table-driven exp for the MFMA variant: x = (64 m + j) ln2/64 + r with |r| <= ln2/128, so
+// exp(x) = 2^m * 2^(j/64) * exp(r) with a degree-5 polynomial (r^6/720 < 2^-56) and the 64
+// correctly rounded values of 2^(j/64) in LDS: 13 fp64 issue slots instead of 18, plus three
+// integer instructions and one ds_read_b64.  Error < 2 ulp (the polynomial form: < 1 ulp).
+#ifndef APAP_TABLE_EXP
+#define APAP_TABLE_EXP 1
+#endif
+__constant__ double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+
+__device__ __forceinline__ double exp_nonpos_tab(double x, const double *tab /* LDS */) {
+    x = fmax(x, -1100.0);
+    const double kf = __builtin_rint(x * 0x1.71547652b82fep+6);   // 64 log2(e)
+    double r = fma(kf, -0x1.62e42fefa39efp-7, x);                   // -ln2/64 high
+    r = fma(kf, -0x1.abc9e3b39803fp-62, r);                         // -ln2/64 low
+    const int ki = (int)kf;
+    const double t = tab[ki & 63];
+    double p = fma(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);  // 1/120, 1/24
+    p = fma(r, p, 0x1.5555555555555p-3);                            // 1/6
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return __builtin_ldexp(t * p, ki >> 6);
+}
+
+__device__ __forceinline__ double cell_weight_sq_tab(double vx, double vy, double sx, double sy,
+                                                     double inv_sigma2, double gamma2, const double *tab) {
+    const double dx = vx - sx;
+    const double dy = vy - sy;
+    const double x = fma(dx, dx, fma(dy, dy, 1e-300));
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return fmax(exp_nonpos_tab(-(g * inv_sigma2), tab), gamma2);
+}
+
 // --------------------------------------------------------------------------------
 // K1 (VALU variant): lanes = cells.  A block is 4 waves on the SAME 64 cells; wave s
 // walks keypoints [slice*ppw, slice*ppw + ppw) of the list, slice = 4*blockIdx.y + s.
@@ -193,6 +249,10 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
                                                        int cells_pad, double gamma2, double inv_sigma2,
                                                        int pts_per_split, double *__restrict__ moments) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
+#if APAP_TABLE_EXP
+    __shared__ double s_exp2[64];
+    if (threadIdx.x < 64) s_exp2[threadIdx.x] = kExp2Tab[threadIdx.x];  // visible after the first barrier
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -248,7 +308,11 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
             const double2 xy = *reinterpret_cast<const double2 *>(buf + lds_off(r, 30));
             const double b0 = *reinterpret_cast<const double *>(buf + lds_off(r, col));
             const double b1 = *reinterpret_cast<const double *>(buf + lds_off(r, 16 + col));
+#if APAP_TABLE_EXP
+            const double w2 = cell_weight_sq_tab(vx, vy, xy.x, xy.y, inv_sigma2, gamma2, s_exp2);
+#else
             const double w2 = cell_weight_sq(vx, vy, xy.x, xy.y, inv_sigma2, gamma2);
+#endif
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
         }
