@@ -68,6 +68,9 @@ SIGNATURES = {
     "apap_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apap_warp_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "apap_warp_rows_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp,
+                                        _vp]),
     "apap_stitch_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
                                      _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "apap_warp_coords_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,

@@ -842,10 +842,13 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
                                               const double *__restrict__ hinv_pad, int mesh_cols,
                                               const int *__restrict__ lut, int final_w, int final_h,
                                               int off_x, int off_y, uint8_t *__restrict__ out,
-                                              const uint8_t *__restrict__ center, int center_h, int center_w) {
+                                              const uint8_t *__restrict__ center, int center_h, int center_w,
+                                              int row_begin, int row_count) {
+    // The launch covers canvas rows [row_begin, row_begin + row_count) - the whole canvas,
+    // or one rank's band when a pair is sharded over GPUs; `out` points at the band's first row.
     // 32-bit pixel indices (the launcher refuses canvases of 2^31 pixels or more): a
     // 64-bit division here expands into ~100 instructions with branches
-    const unsigned total = (unsigned)final_w * (unsigned)final_h;
+    const unsigned total = (unsigned)final_w * (unsigned)row_count;
     const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
     const unsigned g = (blockIdx.x * 256u + threadIdx.x) * 4u;
     if (g >= total) return;
@@ -853,9 +856,10 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
     {
         int i = (int)(g / (unsigned)final_w);
         int j = (int)(g - (unsigned)i * (unsigned)final_w);
+        i += row_begin;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ii[k] = min(i, final_h - 1);  // only the last group can run past the canvas
+            ii[k] = min(i, row_begin + row_count - 1);  // only the last group can run past the band
             jj[k] = j;
             if (++j == final_w) { j = 0; ++i; }
         }
@@ -1172,8 +1176,11 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
                      int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                     void *stream) {
+                     void *stream, int row_begin, int row_count) {
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
+    if (row_begin < 0 || row_count < 0 || (long long)row_begin + row_count > final_h)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_rows_device: rows [%d, %d) outside the canvas of %d rows",
+                          row_begin, row_begin + row_count, final_h);
     if (d_center) {
         // the reference pastes with a numpy slice assignment, which raises when the
         // centre image does not fit the canvas at the offsets
@@ -1196,17 +1203,18 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
     const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
                                  d_Hinv_out, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
     if (rc != APAP_OK) return rc;
-    const size_t total = (size_t)final_w * final_h;
+    if (row_count == 0) return APAP_OK;  // an empty band: only the set-up kernel ran
+    const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
     {
         ProfScope prof(APAP_PROF_WARP, s);
         const dim3 grid((unsigned)((threads + 255) / 256));
         if (d_center)
             hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out, d_center, center_h, center_w);
+                               final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin, row_count);
         else
             hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0);
+                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin, row_count);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
@@ -1219,7 +1227,16 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream) {
     return warp_impl(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
-                     final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream);
+                     final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream, 0, final_h);
+}
+
+int apap_warp_rows_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+                          int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h,
+                          int final_w, int final_h, int off_x, int off_y, int row_begin, int row_count,
+                          uint8_t *d_out_band, void *d_work, size_t work_bytes, int *d_status, void *stream) {
+    return warp_impl(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
+                     final_w, final_h, off_x, off_y, d_out_band, nullptr, d_work, work_bytes, d_status, stream, row_begin,
+                     row_count);
 }
 
 int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
@@ -1230,7 +1247,7 @@ int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t
     if (!d_center) return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: null centre image");
     return warp_impl(d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
                      d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status,
-                     stream);
+                     stream, 0, final_h);
 }
 
 int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,

@@ -55,6 +55,23 @@ def hip_solve(table, denorm, vertices, gamma, sigma):
     return H
 
 
+def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_begin, row_count, out_band, shape):
+    """Default ``warp_fn``: resident-data C-ABI call warping canvas rows
+    ``[row_begin, row_begin + row_count)`` into ``out_band``."""
+    if not img.is_cuda:
+        raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_warp_rows needs CUDA/HIP tensors; there is no CPU fallback")
+    rows, cols = shape
+    nbytes = _native.lib().apap_warp_workspace_bytes(rows, cols, final_w, final_h)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+    status = torch.zeros(1, dtype=torch.int32, device=img.device)
+    stream = torch.cuda.current_stream(img.device).cuda_stream
+    _native.check(_native.lib().apap_warp_rows_device(
+        img.data_ptr(), img.shape[0], img.shape[1], H.data_ptr(), rows, cols, mesh_w.data_ptr(), mesh_w.numel(),
+        mesh_h.data_ptr(), mesh_h.numel(), final_w, final_h, off_x, off_y, row_begin, row_count, out_band.data_ptr(),
+        work.data_ptr(), nbytes, status.data_ptr(), ctypes.c_void_p(stream)))
+    return status
+
+
 class ShardedSolver:
     """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
 
@@ -63,8 +80,8 @@ class ShardedSolver:
     rank (what a following sharded warp needs for its own rows, and what rank 0 writes).
     """
 
-    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve):
-        self.pair, self.dev, self.dist, self.solve_fn = pair, dev, dist, solve_fn
+    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows):
+        self.pair, self.dev, self.dist, self.solve_fn, self.warp_fn = pair, dev, dist, solve_fn, warp_fn
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.rows, self.cols = pair.vertices.shape[:2]
@@ -104,9 +121,44 @@ class ShardedSolver:
             self.H[ra * self.cols:rb * self.cols].copy_(self._gather[r, :(rb - ra) * self.cols])
         return self.H
 
+    def _warp_setup(self):
+        """Once per pair: the source image reaches every rank by a broadcast from rank 0
+        (25 MB at 4K, 100 MB at 8K - the transfer SURVEY.md 8e warns dominates a single
+        warp); canvas rows are dealt in contiguous near-equal bands."""
+        p, d = self.pair, self.dist
+        self.bands = row_partition(p.final_h, self.world)
+        self.max_band = max(b - a for a, b in self.bands)
+        if self.rank == 0 and p.img is not None:
+            self.img = torch.from_numpy(np.ascontiguousarray(p.img)).to(self.dev)
+        else:
+            self.img = torch.zeros(p.shape, dtype=torch.uint8, device=self.dev)
+        if d is not None and self.world > 1:
+            d.broadcast(self.img, src=0)
+        self.mesh_w = torch.from_numpy(np.ascontiguousarray(p.mesh[0])).to(self.dev)
+        self.mesh_h = torch.from_numpy(np.ascontiguousarray(p.mesh[1])).to(self.dev)
+        self._band = torch.zeros((self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
+        self._bands = torch.zeros((self.world, self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
+        self.out = torch.zeros((p.final_h, p.final_w, 3), dtype=torch.uint8, device=self.dev)
+
     def warp(self, stream=None):
-        raise NotImplementedError("row-banded warp of one pair is not built yet (SURVEY.md 8e: "
-                                  "transfer-dominated); use --mode pairs")
+        """Backward warp of the pair with canvas rows sharded over the ranks: every rank
+        warps its band from the full H grid (present on every rank after ``solve``), one
+        all-gather assembles the canvas on every rank.  Returns ``self.out``."""
+        if not hasattr(self, "img"):
+            self._warp_setup()
+        p, d = self.pair, self.dist
+        a, b = self.bands[self.rank]
+        st = self.warp_fn(self.img, self.H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
+                          self._band, (self.rows, self.cols))
+        if st is not None:
+            self.status = st
+        if d is None or self.world == 1:
+            self.out.copy_(self._band[:b - a])
+            return self.out
+        d.all_gather_into_tensor(self._bands.view(-1, p.final_w, 3), self._band)
+        for r, (ra, rb) in enumerate(self.bands):
+            self.out[ra:rb].copy_(self._bands[r, :rb - ra])
+        return self.out
 
 
 def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):

@@ -195,6 +195,14 @@ int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream);
 
+/* apap_warp_device restricted to canvas rows [row_begin, row_begin + row_count): what one
+ * rank computes when the warp of ONE pair is sharded over GPUs (cvx_proj_amd/dist.py).
+ * d_out_band receives row_count x final_w x 3 bytes. */
+int apap_warp_rows_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+                          int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h,
+                          int final_w, int final_h, int off_x, int off_y, int row_begin, int row_count,
+                          uint8_t *d_out_band, void *d_work, size_t work_bytes, int *d_status, void *stream);
+
 /* Resident-data twin of apap_local_stitch. */
 int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
                        int center_w, const float *d_Hfwd, int mesh_rows, int mesh_cols,

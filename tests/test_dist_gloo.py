@@ -41,6 +41,18 @@ def oracle_solve(table, denorm, vertices, gamma, sigma):
     return torch.from_numpy(h.astype(np.float32).reshape(-1, 9))
 
 
+def oracle_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_begin, row_count, out_band, shape):
+    """CPU stand-in with the ``warp_fn`` contract (warps the whole canvas, keeps the band)."""
+    from oracle import apap_oracle as O
+    rows, cols = shape
+    Hn = H.cpu().numpy().reshape(rows, cols, 3, 3)
+    hinv = np.linalg.inv(Hn.astype(np.float64)).astype(np.float32)
+    full = O.local_warp_fast(img.cpu().numpy(), hinv, (mesh_w.cpu().numpy(), mesh_h.cpu().numpy()),
+                             (final_w, final_h), (off_x, off_y))
+    out_band[:row_count].copy_(torch.from_numpy(full[row_begin:row_begin + row_count]))
+    return None
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -57,17 +69,21 @@ def worker(rank, world, port, rows, q):
         from cvx_proj_amd.synth import synth_pair
         p = synth_pair(640, 480, 150, rows, seed=21)        # rows x rows mesh
         p.vertices = p.vertices[:, :rows + 2] if rows > 3 else p.vertices   # non-square is fine
-        s = ShardedSolver(p, torch.device("cpu"), dist, solve_fn=oracle_solve)
+        if rank != 0:
+            p.img = None                                        # only rank 0 owns the source image
+        s = ShardedSolver(p, torch.device("cpu"), dist, solve_fn=oracle_solve, warp_fn=oracle_warp_rows)
         if rank != 0:
             assert float(s.table.abs().sum()) == 0.0            # only rank 0 holds the table before solve()
         H = s.solve().numpy().copy()
         assert float(s.table.abs().sum()) > 0.0                  # broadcast arrived
+        canvas = s.warp().numpy().copy()                         # image broadcast + banded warp + all-gather
+        assert s.bands[0][0] == 0 and s.bands[-1][1] == p.final_h
         pairs = [synth_pair(320, 240, 60, 4, seed=100 + k) for k in range(5)]
         grids = solve_pairs(pairs, torch.device("cpu"), dist, solve_fn=oracle_solve)
-        q.put((rank, s.parts, H, grids))
+        q.put((rank, s.parts, H, grids, canvas))
     except Exception as e:          # surface the failure instead of letting the parent time out
         import traceback
-        q.put((rank, "ERROR", traceback.format_exc(), None))
+        q.put((rank, "ERROR", traceback.format_exc(), None, None))
         raise
     finally:
         dist.destroy_process_group()
@@ -92,11 +108,18 @@ def test_sharded_solver_two_ranks(rows):
     p = synth_pair(640, 480, 150, rows, seed=21)
     verts = p.vertices[:, :rows + 2] if rows > 3 else p.vertices
     H_ref, _ = O.local_homography_fast(p.src, p.dst, verts, p.gamma, p.sigma)
-    for rank, parts, H, grids in res:
+    hinv_ref = np.linalg.inv(H_ref.astype(np.float64)).astype(np.float32)
+    canvas_ref = O.local_warp_fast(p.img, hinv_ref, (p.mesh[0], p.mesh[1]), (p.final_w, p.final_h), (p.off_x, p.off_y))
+    for rank, parts, H, grids, canvas in res:
+        # the warp ran on each rank's own H; the H grids equal the reference's to rounding, so
+        # the canvases must agree except where a coordinate sits on an integer boundary
+        assert np.mean((canvas != canvas_ref).any(axis=-1)) < 1e-4
+        assert canvas.any()
         assert parts == res[0][1] and parts[0][0] == 0 and parts[-1][1] == verts.shape[0]
         H = H.reshape(verts.shape[0], verts.shape[1], 3, 3)
         assert O.reprojection_rmse_delta(H, H_ref, p.src).max() < 1e-6     # full grid on EVERY rank
     assert np.array_equal(res[0][2], res[1][2])
+    assert np.array_equal(res[0][4], res[1][4])                  # same canvas on every rank
     assert res[1][3] is None
     grids = res[0][3]
     assert len(grids) == 5

@@ -399,3 +399,32 @@ def test_stitch_centre_must_fit_canvas(native):
     with pytest.raises(native.ApapError) as e:
         native.local_stitch(img, np.zeros((16, 16, 3), np.uint8), H, [0.0, 8.0, 16.0], [0.0, 8.0, 16.0], 16, 16, 1, 0)
     assert e.value.code == native.ERR_INVALID_ARG
+
+
+def test_row_banded_warp_equals_full_warp(native, golden):
+    """apap_warp_rows_device over uneven bands reassembles the full canvas bit for bit (what
+    the ranks of a sharded single-pair warp compute), and ShardedSolver.warp on one rank
+    equals the host-buffer entry point."""
+    import torch
+    from cvx_proj_amd.dist import ShardedSolver, hip_warp_rows
+    p = config_pair("C2")
+    s = ShardedSolver(p, torch.device("cuda:0"), None)
+    s.solve()
+    full = s.warp().cpu().numpy()
+    H = s.H.cpu().numpy().reshape(100, 100, 3, 3)
+    ref, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    assert np.array_equal(full, ref)
+    bands = [(0, 1), (1, 300), (300, 301), (301, 777), (777, p.final_h)]
+    out = torch.zeros_like(s.out)
+    for a, b in bands:
+        band = torch.zeros((b - a, p.final_w, 3), dtype=torch.uint8, device=out.device)
+        st = hip_warp_rows(s.img, s.H, s.mesh_w, s.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a, band, (100, 100))
+        assert int(st.cpu()[0]) == 0
+        out[a:b] = band
+    assert np.array_equal(out.cpu().numpy(), ref)
+    # rows outside the canvas are refused
+    rc = native.lib().apap_warp_rows_device(s.img.data_ptr(), p.shape[0], p.shape[1], s.H.data_ptr(), 100, 100,
+                                            s.mesh_w.data_ptr(), 101, s.mesh_h.data_ptr(), 101, p.final_w, p.final_h,
+                                            p.off_x, p.off_y, p.final_h - 1, 2, out.data_ptr(), out.data_ptr(), 1 << 30,
+                                            out.data_ptr(), None)
+    assert rc == native.ERR_INVALID_ARG
