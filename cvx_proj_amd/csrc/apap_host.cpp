@@ -38,6 +38,18 @@ float pairwise_sum_f32(const float *a, long n) {
     return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
 }
 
+// numpy's add.reduce over n contiguous float32 values: the reduction iterator hands the
+// inner loop at most 8192 elements (the ufunc buffer size) at a time, each piece is summed
+// pairwise and the pieces are accumulated left to right.  Verified against numpy for n up
+// to 40 000, for 1-D arrays and for the column-major view of getNormalize2DPts' output.
+float numpy_sum_f32(const float *a, long n) {
+    const long kBuf = 8192;
+    if (n <= kBuf) return pairwise_sum_f32(a, n);
+    float res = pairwise_sum_f32(a, kBuf);
+    for (long lo = kBuf; lo < n; lo += kBuf) res += pairwise_sum_f32(a + lo, n - lo < kBuf ? n - lo : kBuf);
+    return res;
+}
+
 // add.reduce along axis 0 of an (n, 2) C-contiguous float32 array: numpy walks the
 // rows and adds each into the 2-element output, i.e. plain sequential sums.
 void column_sums_f32(const float *p, int n, float &s0, float &s1) {
@@ -63,7 +75,7 @@ void normalize_2d_pts(const float *pts, int n, float t[9], float *out) {
         const float sx = dx * dx, sy = dy * dy;
         dist[i] = std::sqrt(sx + sy);
     }
-    const float mean_dist = div_count(pairwise_sum_f32(dist.data(), n), n);
+    const float mean_dist = div_count(numpy_sum_f32(dist.data(), n), n);
     // np.float32 + python float stays float32 (NEP 50); np.sqrt(2) is a float64.
     const float denom = mean_dist + (float)1e-8;
     const double scale = std::sqrt(2.0) / (double)denom;
@@ -95,14 +107,14 @@ void conditioner_from_pts(const float *pts, int n, float T[9]) {
         col0[i] = pts[2 * i];
         col1[i] = pts[2 * i + 1];
     }
-    const float m0 = div_count(pairwise_sum_f32(col0.data(), n), n);
-    const float m1 = div_count(pairwise_sum_f32(col1.data(), n), n);
+    const float m0 = div_count(numpy_sum_f32(col0.data(), n), n);
+    const float m1 = div_count(numpy_sum_f32(col1.data(), n), n);
     for (int i = 0; i < n; ++i) {
         const float d0 = col0[i] - m0, d1 = col1[i] - m1;
         col0[i] = d0 * d0;
         col1[i] = d1 * d1;
     }
-    const float q0 = pairwise_sum_f32(col0.data(), n), q1 = pairwise_sum_f32(col1.data(), n);
+    const float q0 = numpy_sum_f32(col0.data(), n), q1 = numpy_sum_f32(col1.data(), n);
     float sd0 = std::sqrt(div_count(q0, n)), sd1 = std::sqrt(div_count(q1, n));
     // std * std * n / (n - 1), all float32
     const float fn = (float)n, fn1 = (float)(n - 1);

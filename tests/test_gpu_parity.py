@@ -428,3 +428,48 @@ def test_row_banded_warp_equals_full_warp(native, golden):
                                             p.off_x, p.off_y, p.final_h - 1, 2, out.data_ptr(), out.data_ptr(), 1 << 30,
                                             out.data_ptr(), None)
     assert rc == native.ERR_INVALID_ARG
+
+
+# ------------------------------------------------------------------ parameter edge cases
+@pytest.mark.parametrize("gamma,sigma", [(0.0, 30.0), (-1.0, 30.0), (0.5, 1e4), (0.9, 8.0), (1.5, 50.0)])
+def test_gamma_sigma_ranges_vs_oracle(native, gamma, sigma):
+    """gamma = 0 (no clamp), negative gamma (never clamps), huge sigma (all weights ~1),
+    gamma close to 1, gamma > 1 (everything clamped above 1)."""
+    p = synth_pair(640, 480, 300, 7, seed=3)
+    H, W = native.local_homography(p.src, p.dst, p.vertices, gamma, sigma)
+    H_ref, W_ref = O.local_homography_loop(p.src, p.dst, p.vertices, gamma, sigma)
+    assert np.allclose(W, W_ref, rtol=1e-14, atol=1e-300)
+    assert report(f"gamma={gamma} sigma={sigma}", H, H_ref, p.src).max() < RMSE_BAR
+
+
+def test_all_weights_underflow_does_not_hang(native):
+    """sigma so small that exp underflows to 0 and gamma = 0: the normal matrix is exactly
+    zero; the solver must terminate (Jacobi fallback on a zero matrix) - values are whatever
+    a zero system gives, the reference returns an arbitrary basis vector too."""
+    p = synth_pair(640, 480, 50, 3, seed=8)
+    H, W = native.local_homography(p.src, p.dst, p.vertices + 1e4, 0.0, 1e-2)
+    assert (W == 0).all() and H.shape == (3, 3, 3, 3)
+
+
+def test_many_keypoints_and_splits(native, variant):
+    """n = 20 000 (more keypoints than any config; exercises the chunk loop, partial last
+    chunk and several grid-level splits on a small mesh)."""
+    p = synth_pair(1920, 1080, 20001, 6, seed=12)
+    H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    H_ref, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
+    assert report("n=20001", H, H_ref, p.src[:256]).max() < RMSE_BAR
+
+
+def test_mesh_with_more_edges_than_the_lds_lookup_holds(native):
+    """More than 4096 edges on an axis: the set-up falls back to the separate inversion and
+    linear-scan lookup kernels."""
+    rng = np.random.default_rng(5)
+    cols = 4200
+    fw, fh = cols * 2, 6
+    img = rng.integers(1, 256, (fh, fw, 3), dtype=np.uint8)
+    H = np.tile(np.eye(3, dtype=np.float32), (1, cols, 1, 1))
+    H[0, ::2, 0, 2] = 1.0                                     # every other cell shifts by one pixel
+    mesh_w, mesh_h = np.linspace(0, fw, cols + 1), np.linspace(0, fh, 2)
+    out, hinv = native.local_warp(img, H, mesh_w, mesh_h, fw, fh, 0, 0)
+    ref = O.local_warp_fast(img, np.linalg.inv(H.astype(np.float64)).astype(np.float32), (mesh_w, mesh_h), (fw, fh), (0, 0))
+    assert np.array_equal(out, ref) and out.any()

@@ -27,7 +27,9 @@ def test_c_prepare_matches_reference_vectors(native, golden, name):
 
 def test_c_prepare_matches_oracle_random(native):
     rng = np.random.default_rng(3)
-    sizes = [2, 3, 7, 8, 9, 127, 128, 129, 1000, 2000, 5000] + [int(v) for v in rng.integers(10, 6000, 40)]
+    # beyond 8192 numpy's reductions run in buffer-sized pieces: cover that regime too
+    sizes = ([2, 3, 7, 8, 9, 127, 128, 129, 1000, 2000, 5000, 8191, 8192, 8193, 10000, 16385, 20001, 40000]
+             + [int(v) for v in rng.integers(10, 6000, 30)] + [int(v) for v in rng.integers(8193, 50000, 10)])
     for t, n in enumerate(sizes):
         w, h = rng.choice([200, 1920, 3840, 7680]), rng.choice([140, 1080, 2160, 4320])
         src = (rng.random((n, 2)) * [w, h]).astype(np.float32)
