@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -144,7 +145,9 @@ int apap_local_homography(const float *src, const float *dst, int n, const doubl
     APAP_HIP_TRY(hipMemcpyAsync(H_out, d_H, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     if (W_out) {
         // stream the weight tensor through a bounded device buffer (it is 8 n bytes per cell)
-        const size_t max_bytes = (size_t)1 << 30;
+        // 1 GiB of device staging by default; APAP_W_CHUNK_BYTES lets tests force several chunks
+        const char *env = getenv("APAP_W_CHUNK_BYTES");
+        const size_t max_bytes = (env && atoll(env) > 0) ? (size_t)atoll(env) : ((size_t)1 << 30);
         int chunk = (int)(max_bytes / ((size_t)n * sizeof(double)));
         if (chunk < 1) chunk = 1;
         if (chunk > cells) chunk = cells;

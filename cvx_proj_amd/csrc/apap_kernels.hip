@@ -159,7 +159,7 @@ __device__ __forceinline__ double cell_weight_sq_tab(double vx, double vy, doubl
 
 // --------------------------------------------------------------------------------
 // K1 (VALU variant): lanes = cells.  A block is 4 waves on the SAME 64 cells; wave s
-// walks keypoints [slice*ppw, slice*ppw + ppw) of the list, slice = 4*blockIdx.y + s.
+// walks its quarter of the block's keypoint split (split = blockIdx.y).
 // Per keypoint the 32 table doubles are wave-uniform: they arrive through the scalar
 // cache into SGPRs and feed v_fma_f64 as the scalar operand, so the vector unit only
 // executes the weight and 30 FMAs.  The four partial sums are added in LDS in a fixed

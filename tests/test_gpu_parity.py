@@ -19,7 +19,6 @@ pytestmark = pytest.mark.gpu
 
 RMSE_BAR = 1e-4          # px, north_star
 TINY = ["tiny_sigma100", "tiny_sigma6"]
-VARIANTS = [1, 2]        # APAP_VARIANT_VALU, APAP_VARIANT_MFMA
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -125,7 +124,6 @@ def test_no_spectral_gap_falls_back_to_jacobi(native):
         native.lib().apap_set_eigen_solver(prev)
     assert np.isfinite(out["invit"]).all()
     H_ref, _ = O.local_homography_loop(src, dst, verts, 0.5, 30.0, want_weights=False)
-    M = None
     d_j = O.reprojection_rmse_delta(out["jacobi"], H_ref, src)
     d_i = O.reprojection_rmse_delta(out["invit"], H_ref, src)
     print(f"no-gap case: jacobi vs oracle {d_j.max():.2e} px, invit vs oracle {d_i.max():.2e} px, "
@@ -473,3 +471,16 @@ def test_mesh_with_more_edges_than_the_lds_lookup_holds(native):
     out, hinv = native.local_warp(img, H, mesh_w, mesh_h, fw, fh, 0, 0)
     ref = O.local_warp_fast(img, np.linalg.inv(H.astype(np.float64)).astype(np.float32), (mesh_w, mesh_h), (fw, fh), (0, 0))
     assert np.array_equal(out, ref) and out.any()
+
+
+def test_weight_tensor_streams_in_chunks(native, golden, monkeypatch):
+    """The (cells, n) weight tensor is produced through a bounded device buffer; with the
+    bound forced down to 1 MB the C2 tensor (40 MB) crosses it 40 times."""
+    monkeypatch.setenv("APAP_W_CHUNK_BYTES", str(1 << 20))
+    g = golden("c2_ref")
+    p = config_pair("C2", with_image=False)
+    _, W = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=True)
+    assert np.allclose([W.sum(), (W * W).sum()], g["W_checksum"], rtol=1e-13)
+    assert np.allclose(W[0, 0], g["W_row0"], rtol=1e-14) and np.allclose(W[-1, -1], g["W_last"], rtol=1e-14)
+    mid = O.cell_weights(p.vertices[37, 61], p.src, p.gamma, p.sigma)
+    assert np.allclose(W[37, 61], mid, rtol=1e-14)
