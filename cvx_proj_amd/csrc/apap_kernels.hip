@@ -1038,16 +1038,17 @@ SolvePlan plan_solve(int n, int cells, int variant) {
     // Fill the chip (256 CUs x 4 SIMDs): aim at >= 4 waves per SIMD (also evens out the
     // blocks-per-CU imbalance: 2500 waves leave SIMDs with 2 or 3, 5000 with 4 or 5).  Small meshes split
     // the keypoint list over grid.y; each split writes its own moment slab and K2 adds
-    // the slabs in a fixed order.  Keep >= 256 keypoints per split.
+    // the slabs in a fixed order.  A split is at least one 64-keypoint LDS chunk and a whole
+    // number of chunks (a partial chunk costs as much as a full one in the MFMA kernel).
     int splits = 1;
     static const int want_waves = [] {
         const char *e = getenv("APAP_WANT_WAVES");  // tuning knob for tools/sweep.py
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 4096;
     }();
-    while (splits < 16 && p.cell_tiles * 4 * splits < want_waves && n / (splits * 2) >= 256) splits *= 2;
+    while (splits < 32 && p.cell_tiles * 4 * splits < want_waves && n / (splits * 2) >= 64) splits *= 2;
     int pps = (n + splits - 1) / splits;
-    pps = (pps + 3) / 4 * 4;
+    pps = (pps + 63) / 64 * 64;
     p.splits = (n + pps - 1) / pps;  // no empty split
     p.pts_per_split = pps;
     p.moment_bytes = (size_t)p.splits * kMoments * p.cells_pad * sizeof(double);
