@@ -11,6 +11,8 @@ out = sys.argv[1]
 
 
 def short(name):
+    if "k_warp<true>" in name or "k_warpILb1E" in name:
+        return "k_warp<stitch>"
     for k in ("k_assemble_valu", "k_assemble_mfma", "k_eigen_denorm", "k_invert_cells", "k_cell_lut", "k_warp_coords",
               "k_warp_setup", "k_warp", "k_flatten", "k_weights", "k_blend"):
         if k in name:
