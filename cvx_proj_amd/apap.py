@@ -111,9 +111,11 @@ class APAP:
         mesh_w, mesh_h = mesh
         ori_h, ori_w, _ = ori_img.shape
         mesh_n, pt_size, _, _ = local_homography.shape
+        print("Inverse solving started.")        # the reference prints these two lines (apap.py:200,204);
         warped, hinv = _native.local_warp(ori_img, local_homography, mesh_w, mesh_h, self.final_width,
                                           self.final_height, self.offset_x, self.offset_y,
                                           want_inverse=True, device=self.device)
+        print("Inverse solving completed.")      # here the inverses come from the same native call as the warp
         if isinstance(local_homography, np.ndarray) and local_homography.flags.writeable:
             local_homography[...] = hinv
         return warped
