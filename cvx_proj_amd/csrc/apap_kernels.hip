@@ -796,7 +796,9 @@ struct Hinv9 {
 };
 
 __device__ __forceinline__ Hinv9 load_hinv(const double *__restrict__ hinv_pad, unsigned cell) {
-    const double2 *p = reinterpret_cast<const double2 *>(hinv_pad) + cell * (APAP_HINV_STRIDE / 2);
+    // unsigned 32-bit byte offset: lets the load use the scalar-base + 32-bit-offset form
+    const double2 *p = reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(hinv_pad) +
+                                                         (size_t)(cell * (unsigned)(APAP_HINV_STRIDE * sizeof(double))));
     Hinv9 h;
     h.a = p[0]; h.b = p[1]; h.c = p[2]; h.d = p[3]; h.e = p[4];
     return h;
@@ -866,10 +868,11 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
     }
     // Lookups.  The four pixels share a canvas row unless the group wraps, so two row
     // lookups (first and last pixel) serve all four.
-    const int r0 = lut[ii[0]], r3 = lut[ii[3]];
+    const int r0 = lut[(unsigned)ii[0]], r3 = lut[(unsigned)ii[3]];
     int cell[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cell[k] = (ii[k] == ii[0] ? r0 : r3) * mesh_cols + lut[final_h + jj[k]];
+    for (int k = 0; k < 4; ++k)
+        cell[k] = (ii[k] == ii[0] ? r0 : r3) * mesh_cols + lut[(unsigned)(final_h + jj[k])];
     // H^-1 of the first and the last pixel's cells; the two in between almost always sit in
     // one of those (cell indices are monotone along a row and cells are wider than 2 px).
     Hinv9 hv[4];

@@ -1,0 +1,54 @@
+/* A host in plain C driving the engine through the C ABI alone (no Python, no torch):
+ *   gcc -O2 examples/c_host.c -Iinclude -Lcvx_proj_amd -lapap_hip -Wl,-rpath,$PWD/cvx_proj_amd -lm -o c_host && ./c_host
+ * Builds a small synthetic pair, runs local_homography, local_warp and the output stage,
+ * prints checksums (tests/test_gpu_parity.py compares them with the Python binding's). */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "apap_hip.h"
+
+static unsigned lcg(unsigned *s) { *s = *s * 1664525u + 1013904223u; return *s >> 8; }
+
+int main(void) {
+    enum { N = 200, ROWS = 12, COLS = 15, W = 320, Hh = 240 };
+    if (apap_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
+    unsigned seed = 7;
+    float *src = malloc(sizeof(float) * 2 * N), *dst = malloc(sizeof(float) * 2 * N);
+    for (int i = 0; i < N; ++i) {
+        const float x = (float)(lcg(&seed) % (W * 16)) / 16.0f, y = (float)(lcg(&seed) % (Hh * 16)) / 16.0f;
+        src[2 * i] = x; src[2 * i + 1] = y;
+        dst[2 * i] = 1.01f * x + 0.02f * y + 4.0f + (float)(lcg(&seed) % 64) / 64.0f;
+        dst[2 * i + 1] = -0.015f * x + 0.99f * y + 3.0f + (float)(lcg(&seed) % 64) / 64.0f;
+    }
+    const int fw = W + 8, fh = Hh + 6, ox = 0, oy = 0;
+    double *vert = malloc(sizeof(double) * ROWS * COLS * 2), mesh_w[COLS + 1], mesh_h[ROWS + 1];
+    for (int r = 0; r < ROWS; ++r)
+        for (int c = 0; c < COLS; ++c) {
+            vert[(r * COLS + c) * 2] = (c + 0.5) * fw / COLS;
+            vert[(r * COLS + c) * 2 + 1] = (r + 0.5) * fh / ROWS;
+        }
+    for (int c = 0; c <= COLS; ++c) mesh_w[c] = (double)c * fw / COLS;
+    for (int r = 0; r <= ROWS; ++r) mesh_h[r] = (double)r * fh / ROWS;
+    float *H = malloc(sizeof(float) * ROWS * COLS * 9);
+    int rc = apap_local_homography(src, dst, N, vert, ROWS, COLS, 0.5, 100.0, H, NULL, -1);
+    if (rc) { fprintf(stderr, "local_homography: %s\n", apap_last_error()); return 1; }
+    unsigned char *img = malloc((size_t)W * Hh * 3), *out = malloc((size_t)fw * fh * 3);
+    for (size_t i = 0; i < (size_t)W * Hh * 3; ++i) img[i] = (unsigned char)(lcg(&seed) & 0xff);
+    rc = apap_local_warp(img, Hh, W, H, ROWS, COLS, mesh_w, COLS + 1, mesh_h, ROWS + 1, fw, fh, ox, oy, out, NULL, -1);
+    if (rc) { fprintf(stderr, "local_warp: %s\n", apap_last_error()); return 1; }
+    double *flat = malloc(sizeof(double) * ROWS * COLS * 9);
+    rc = apap_invert_normalize_flatten(H, ROWS * COLS, flat, -1);
+    if (rc) { fprintf(stderr, "flatten: %s\n", apap_last_error()); return 1; }
+    double hs = 0.0, fs = 0.0;
+    unsigned long long ps = 0;
+    for (int i = 0; i < ROWS * COLS * 9; ++i) { hs += fabs((double)H[i]); fs += fabs(flat[i]); }
+    for (size_t i = 0; i < (size_t)fw * fh * 3; ++i) ps += out[i];
+    printf("%s\nH_abs_sum %.9e\nflat_abs_sum %.9e\npixel_sum %llu\n", apap_version(), hs, fs, ps);
+    /* error path: a mesh that does not cover the canvas is an index error, not a crash */
+    mesh_h[ROWS] = fh - 10.0;
+    rc = apap_local_warp(img, Hh, W, H, ROWS, COLS, mesh_w, COLS + 1, mesh_h, ROWS + 1, fw, fh, ox, oy, out, NULL, -1);
+    printf("uncovered_mesh_rc %d (%s)\n", rc, rc == APAP_ERR_INDEX ? "APAP_ERR_INDEX" : "unexpected");
+    free(src); free(dst); free(vert); free(H); free(img); free(out); free(flat);
+    return rc == APAP_ERR_INDEX ? 0 : 1;
+}

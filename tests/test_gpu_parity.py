@@ -484,3 +484,54 @@ def test_weight_tensor_streams_in_chunks(native, golden, monkeypatch):
     assert np.allclose(W[0, 0], g["W_row0"], rtol=1e-14) and np.allclose(W[-1, -1], g["W_last"], rtol=1e-14)
     mid = O.cell_weights(p.vertices[37, 61], p.src, p.gamma, p.sigma)
     assert np.allclose(W[37, 61], mid, rtol=1e-14)
+
+
+def test_plain_c_host_uses_the_abi(native, tmp_path):
+    """examples/c_host.c: a C program linked against libapap_hip.so (no Python, no torch in
+    that process) produces the same numbers as the ctypes binding on the same inputs."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "c_host")
+    libdir = os.path.join(root, "cvx_proj_amd")
+    subprocess.run(["gcc", "-O2", os.path.join(root, "examples", "c_host.c"), "-I" + os.path.join(root, "include"),
+                    "-L" + libdir, "-lapap_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm", "-o", exe],
+                   check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    vals = dict(re.findall(r"(\w+) ([0-9.e+]+)", r.stdout))
+    assert "APAP_ERR_INDEX" in r.stdout
+
+    # the same inputs, regenerated with the program's LCG, through the Python binding
+    state = [7]
+
+    def lcg():
+        state[0] = (state[0] * 1664525 + 1013904223) & 0xFFFFFFFF
+        return state[0] >> 8
+    N_, ROWS, COLS, W, Hh = 200, 12, 15, 320, 240
+    src = np.zeros((N_, 2), np.float32)
+    dst = np.zeros((N_, 2), np.float32)
+    f = np.float32
+    for i in range(N_):
+        x = f(lcg() % (W * 16)) / f(16.0)
+        y = f(lcg() % (Hh * 16)) / f(16.0)
+        src[i] = (x, y)
+        dst[i, 0] = f(f(f(f(1.01) * x) + f(f(0.02) * y)) + f(4.0)) + f(lcg() % 64) / f(64.0)
+        dst[i, 1] = f(f(f(f(-0.015) * x) + f(f(0.99) * y)) + f(3.0)) + f(lcg() % 64) / f(64.0)
+    fw, fh = W + 8, Hh + 6
+    cc, rr = np.meshgrid(np.arange(COLS), np.arange(ROWS))
+    vert = np.stack([(cc + 0.5) * fw / COLS, (rr + 0.5) * fh / ROWS], axis=-1)
+    mesh_w = np.arange(COLS + 1, dtype=np.float64) * fw / COLS
+    mesh_h = np.arange(ROWS + 1, dtype=np.float64) * fh / ROWS
+    H, _ = native.local_homography(src, dst, vert, 0.5, 100.0, want_weights=False)
+    img = np.array([lcg() & 0xFF for _ in range(W * Hh * 3)], dtype=np.uint8).reshape(Hh, W, 3)
+    out, _ = native.local_warp(img, H, mesh_w, mesh_h, fw, fh, 0, 0)
+    flat = native.invert_normalize_flatten(H)
+    # gcc may contract a*b+c into an FMA for the float keypoints on some targets: compare to 1e-6
+    assert np.isclose(float(vals["H_abs_sum"]), np.abs(H.astype(np.float64)).sum(), rtol=1e-6)
+    assert np.isclose(float(vals["flat_abs_sum"]), np.abs(flat).sum(), rtol=1e-6)
+    assert abs(int(vals["pixel_sum"]) - int(out.astype(np.uint64).sum())) <= 0.001 * int(vals["pixel_sum"])
