@@ -106,7 +106,7 @@ class Resident:
                                            self.status.data_ptr(), ctypes.c_void_p(stream)))
 
 
-def cpu_baseline(cfg, budget_cells, budget_rows):
+def cpu_baseline(cfg, budget_cells, budget_rows, pool_workers=0):
     """The oracle's faithful-loop port on this host: a bounded, seeded sample of the
     same workload (cells spread over the mesh; every k-th canvas row)."""
     from oracle import apap_oracle as O
@@ -125,7 +125,16 @@ def cpu_baseline(cfg, budget_cells, budget_rows):
     O.local_warp_loop(p.img, hinv, p.mesh, (p.final_w, p.final_h), (p.off_x, p.off_y), rows_subset=sub)
     t_warp = time.perf_counter() - t0
     # the in-place inversion of all cells is part of local_warp; it is inside t_warp, as in the reference
+    pool = None
+    if pool_workers > 1:
+        # "best-effort CPU" row of BASELINE.md: the same loop over a process pool, 1 BLAS thread each
+        Hp, t_pool = O.local_homography_pool(p.src, p.dst, p.vertices, p.gamma, p.sigma, cells, pool_workers)
+        assert np.array_equal(Hp, H)
+        pool = {"value": len(cells) / t_pool, "unit": "homographies/s", "cores": pool_workers, "kind": "port",
+                "sample": f"same {len(cells)} cells over a {pool_workers}-process pool (1 BLAS thread each; worker "
+                          f"start-up excluded), {t_pool:.2f} s"}
     return {
+        "pool": pool,
         "value": len(cells) / t_solve, "unit": "homographies/s", "cores": 1, "kind": "port",
         "sample": f"{len(cells)} of {rows * cols} cells (seeded random), {len(sub)} of {p.final_h} canvas rows + all "
                   f"{rows * cols} cell inversions; oracle faithful-loop numpy port, OPENBLAS_NUM_THREADS=1, "
@@ -146,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cells", type=int, default=40000)
     ap.add_argument("--cpu-rows", type=int, default=400)
+    ap.add_argument("--cpu-pool", type=int, default=16, help="workers of the process-pool CPU row (0 = skip)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -278,7 +288,8 @@ def main():
                 "traffic": traffic_warp},
         }
         if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows)
+            line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows,
+                                                min(a.cpu_pool, os.cpu_count() or 1))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

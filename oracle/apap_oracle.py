@@ -37,7 +37,7 @@ import numpy as np
 __all__ = [
     "get_mesh", "get_vertice", "final_size", "uniform_blend",
     "normalize_2d_pts", "conditioner_from_pts", "point_normalize", "dlt_rows",
-    "prepare", "cell_weights", "local_homography_loop", "local_homography_fast",
+    "prepare", "cell_weights", "local_homography_loop", "local_homography_fast", "local_homography_pool",
     "invert_cells_f32", "cell_lookup", "local_warp_loop", "local_warp_fast",
     "warp_coords_fast", "stitch", "invert_normalize_flatten", "project", "reprojection_rmse_delta",
 ]
@@ -212,6 +212,37 @@ def local_homography_loop(src_point, dst_point, vertices, gamma, sigma, cells=No
         _, _, vt = np.linalg.svd(A, full_matrices=False)
         H[i, j] = _denormalise(vt[-1, :], p)
     return H, W
+
+
+def _pool_worker(args):
+    """One worker of ``local_homography_pool``: the faithful loop over a slice of cells."""
+    src, dst, vertices, gamma, sigma, cells = args
+    H, _ = local_homography_loop(src, dst, vertices, gamma, sigma, cells=cells, want_weights=False)
+    return [(i, j, H[i, j]) for i, j in cells]
+
+
+def _pool_ready(_):
+    return 0
+
+
+def local_homography_pool(src_point, dst_point, vertices, gamma, sigma, cells, workers):
+    """"Best-effort CPU" row of BASELINE.md: the faithful per-cell loop spread over a process
+    pool (one BLAS thread per worker).  Used only by bench.py's cpu_baseline leg.  Returns
+    ``(H, seconds)``; the seconds exclude worker start-up (interpreter + imports)."""
+    import multiprocessing as mp
+    import time
+    chunks = [cells[k::workers] for k in range(workers)]
+    ctx = mp.get_context("spawn")      # never fork a process that has initialised the GPU
+    with ctx.Pool(workers) as pool:
+        pool.map(_pool_ready, range(4 * workers))
+        t0 = time.perf_counter()
+        parts = pool.map(_pool_worker, [(src_point, dst_point, vertices, gamma, sigma, c) for c in chunks if c])
+        seconds = time.perf_counter() - t0
+    H = np.zeros(vertices.shape[:2] + (3, 3), dtype=np.float32)
+    for part in parts:
+        for i, j, h in part:
+            H[i, j] = h
+    return H, seconds
 
 
 def moments_from_rows(aa):

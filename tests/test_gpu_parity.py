@@ -317,12 +317,18 @@ def test_cli_writes_reference_mat_layout(native, tmp_path):
 
 
 # ------------------------------------------------------------------ C4 / C5 (multi-GPU configs, one rank)
-def test_c4_full_size_solve_vs_oracle_subset(native):
+def test_c4_full_size_solve_vs_oracle_subset(native, golden):
     """8K pair, 5000 correspondences, 400 x 400 mesh: the whole grid is solved on the GPU;
-    every 5th mesh row is checked against the oracle (the full oracle run takes minutes)."""
+    every 8th mesh row is checked against the REFERENCE's own grid (golden, 7 minutes of its
+    Python loop) and every 5th against the oracle."""
     p = config_pair("C4", with_image=False)
     H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
     assert H.shape == (400, 400, 3, 3) and np.isfinite(H).all()
+    g = golden("c4_ref_rows8")
+    assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
+    every = int(g["keep_rows_every"])
+    d_ref = report("C4 rows ::8 vs reference", H[::every], g["H_ref"], p.src[:128])
+    assert d_ref.max() < RMSE_BAR and np.mean(H[::every] != g["H_ref"]) < 0.01
     sub = p.vertices[::5]
     H_ref, _ = O.local_homography_fast(p.src, p.dst, sub, p.gamma, p.sigma)
     d = report("C4 rows ::5", H[::5], H_ref, p.src[:128])

@@ -92,6 +92,15 @@ def test_config_grids(golden, cfg, name):
         assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
 
 
+def test_c4_rows_vs_reference(golden):
+    """Every 8th mesh row of the 8K / 5000-keypoint / 400 x 400 grid, from the reference."""
+    g = golden("c4_ref_rows8")
+    p = config_pair("C4", with_image=False)
+    every = int(g["keep_rows_every"])
+    H, _ = O.local_homography_fast(p.src, p.dst, p.vertices[::every][:6], p.gamma, p.sigma)
+    assert np.array_equal(H, g["H_ref"][:6])
+
+
 def test_cell_lookup_semantics():
     edges = np.linspace(0, 10, 6)
     c = O.cell_lookup(10, edges)
