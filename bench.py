@@ -165,11 +165,18 @@ def main():
         if world == 1 and a.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; if a rehearsal runs more ranks than GPUs (e.g. 2 gloo ranks on a 1-GPU
+    # box, APAP_BENCH_BACKEND=gloo) the ranks share devices round-robin
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("APAP_BENCH_BACKEND", "nccl")      # nccl = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
 
@@ -178,6 +185,7 @@ def main():
 
     def barrier():
         if dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
