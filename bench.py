@@ -286,6 +286,7 @@ def main():
             "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "hbm_gbs": None if traffic is None else traffic / t_k1 / 1e9,
                          "note": "fp64 FMA work: the f64 matrix and vector pipes share one 78.6 TF datasheet "
                                  "rate (54-59 TF sustained, profiles/r01_peak_fp64.txt); algorithmic 58 flop per "
                                  "(cell, keypoint) counts sqrt and exp as one flop each, the kernel executes "
