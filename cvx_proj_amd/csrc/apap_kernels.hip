@@ -1201,6 +1201,8 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: image of 4 GiB or more");
     if ((unsigned long long)final_w * (unsigned long long)final_h >= (1ull << 31))
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: canvas of 2^31 pixels or more");
+    if ((unsigned long long)mesh_rows * (unsigned long long)mesh_cols * APAP_HINV_STRIDE * sizeof(double) >= (1ull << 32))
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: mesh of 53 million cells or more");
     hipStream_t s = (hipStream_t)stream;
     double *hinv_pad;
     int *lut;
