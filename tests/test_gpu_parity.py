@@ -541,3 +541,29 @@ def test_plain_c_host_uses_the_abi(native, tmp_path):
     assert np.isclose(float(vals["H_abs_sum"]), np.abs(H.astype(np.float64)).sum(), rtol=1e-6)
     assert np.isclose(float(vals["flat_abs_sum"]), np.abs(flat).sum(), rtol=1e-6)
     assert abs(int(vals["pixel_sum"]) - int(out.astype(np.uint64).sum())) <= 0.001 * int(vals["pixel_sum"])
+
+
+def test_device_entry_points_on_a_side_stream(native, golden):
+    """The resident-data entry points enqueue on the stream they are given (here a
+    non-default torch stream) and do not synchronise; results equal the default-stream run."""
+    import ctypes
+    import torch
+    from bench import Resident
+    p = config_pair("C1")
+    dev = torch.device("cuda:0")
+    res = Resident(p, dev)
+    res.solve(0)
+    res.warp(0)
+    torch.cuda.synchronize()
+    H0, out0 = res.H.clone(), res.out.clone()
+    res.H.zero_()
+    res.out.zero_()
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        res.solve(side.cuda_stream)
+        res.warp(side.cuda_stream)
+    side.synchronize()
+    assert torch.equal(res.H, H0) and torch.equal(res.out, out0)
+    assert int(res.status.cpu()[0]) == 0
+    assert np.array_equal(res.H.cpu().numpy().reshape(20, 20, 3, 3), golden("c1_ref")["H_ref"])
