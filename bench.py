@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--mode", default="pairs", choices=["pairs", "cells"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the solve and the warp step into HIP graphs and time graph replays")
     ap.add_argument("--cpu-cells", type=int, default=40000)
     ap.add_argument("--cpu-rows", type=int, default=400)
     ap.add_argument("--cpu-pool", type=int, default=16, help="workers of the process-pool CPU row (0 = skip)")
@@ -206,16 +208,29 @@ def main():
     for _ in range(a.warmup):
         res.solve(stream)
         res.warp(stream)
+    run_solve, run_warp = (lambda: res.solve(stream)), (lambda: res.warp(stream))
+    if a.graph and isinstance(res, Resident):
+        # the entry points only enqueue kernels (no allocation, no synchronisation), so a step
+        # can be captured once and replayed: one host call per step instead of one per kernel
+        torch.cuda.synchronize()
+        g_solve, g_warp = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_solve):
+            res.solve(torch.cuda.current_stream().cuda_stream)
+        with torch.cuda.graph(g_warp):
+            res.warp(torch.cuda.current_stream().cuda_stream)
+        run_solve, run_warp = g_solve.replay, g_warp.replay
+        run_solve()
+        run_warp()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        res.solve(stream)
+        run_solve()
     barrier()
     t_solve = time.perf_counter() - t0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        res.warp(stream)
+        run_warp()
     barrier()
     t_warp = time.perf_counter() - t0
     if dist is not None:
@@ -274,6 +289,7 @@ def main():
             "config": {"workload": f"{a.config}: {CONFIGS[a.config][0]}x{CONFIGS[a.config][1]} pair, "
                                    f"{res.n} correspondences, {res.rows}x{res.cols} mesh, canvas "
                                    f"{pair.final_w}x{pair.final_h}", "mode": a.mode, "variant": a.variant,
+                       "launch": "hip graph replay" if a.graph else "eager",
                        "parallelism": f"{a.mode}x{world}"},
             "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
                      "ms_per_step": t_warp / a.steps * 1e3},

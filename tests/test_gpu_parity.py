@@ -567,3 +567,28 @@ def test_device_entry_points_on_a_side_stream(native, golden):
     assert torch.equal(res.H, H0) and torch.equal(res.out, out0)
     assert int(res.status.cpu()[0]) == 0
     assert np.array_equal(res.H.cpu().numpy().reshape(20, 20, 3, 3), golden("c1_ref")["H_ref"])
+
+
+def test_device_entry_points_are_graph_capturable(native, golden):
+    """solve + warp captured into one HIP graph (no allocation, no synchronisation inside
+    the entry points) and replayed give the same bits as the eager launches."""
+    import torch
+    from bench import Resident
+    p = config_pair("C1")
+    dev = torch.device("cuda:0")
+    res = Resident(p, dev)
+    res.solve(0)
+    res.warp(0)
+    torch.cuda.synchronize()
+    H0, out0 = res.H.clone(), res.out.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        s = torch.cuda.current_stream().cuda_stream
+        res.solve(s)
+        res.warp(s)
+    for _ in range(3):
+        res.H.zero_()
+        res.out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(res.H, H0) and torch.equal(res.out, out0)
