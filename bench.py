@@ -54,21 +54,30 @@ K1_FLOPS_PER_CELL_POINT = 58.0
 
 
 class Resident:
-    """One image pair with everything the hot path reads resident in HBM."""
+    """One image pair (or a batch of pairs sharing mesh and image) with everything the hot
+    path reads resident in HBM."""
 
-    def __init__(self, pair, dev):
+    def __init__(self, pair, dev, batch=1, seed_pairs=None):
         self.pair = pair
+        self.batch = batch
         q = N.host_prepare(pair.src, pair.dst)
         table = N.host_build_table(pair.src, q["cf1"], q["cf2"])
         den = N.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
+        if batch > 1:      # independent keypoint sets (different seeds), same mesh
+            tabs, dens = [table], [den]
+            for extra in seed_pairs:
+                qe = N.host_prepare(extra.src, extra.dst)
+                tabs.append(N.host_build_table(extra.src, qe["cf1"], qe["cf2"]))
+                dens.append(N.host_build_denorm(qe["iC2"], qe["C1"], qe["iN2"], qe["N1"]))
+            table, den = np.stack(tabs), np.stack(dens)
         self.n = len(pair.src)
         self.rows, self.cols = pair.vertices.shape[:2]
         self.cells = self.rows * self.cols
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
         self.table, self.den = t(table), t(den)
         self.vert = t(pair.vertices.reshape(-1, 2))
-        self.H = torch.zeros((self.cells, 9), dtype=torch.float32, device=dev)
-        self.work_bytes = max(N.lib().apap_solve_workspace_bytes(self.n, self.cells), 256)
+        self.H = torch.zeros((batch * self.cells, 9), dtype=torch.float32, device=dev)
+        self.work_bytes = max(N.lib().apap_solve_batch_workspace_bytes(self.n, self.cells, batch), 256)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=dev)
         self.img = t(pair.img)
         self.mesh_w, self.mesh_h = t(pair.mesh[0]), t(pair.mesh[1])
@@ -79,9 +88,9 @@ class Resident:
 
     def solve(self, stream):
         p = self.pair
-        N.check(N.lib().apap_solve_device(self.table.data_ptr(), self.n, self.vert.data_ptr(), self.cells,
-                                          p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(),
-                                          self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
+        N.check(N.lib().apap_solve_batch_device(self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, self.cells,
+                                                p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(), self.batch,
+                                                self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
 
     def warp(self, stream):
         p = self.pair
@@ -153,6 +162,9 @@ def main():
     ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma"])
     ap.add_argument("--mode", default="pairs", choices=["pairs", "cells"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="solve this many independent pairs per step in ONE batched launch (config C5 style); "
+                         "the warp half then runs once per pair")
     ap.add_argument("--graph", action="store_true",
                     help="capture the solve and the warp step into HIP graphs and time graph replays")
     ap.add_argument("--cpu-cells", type=int, default=40000)
@@ -199,9 +211,10 @@ def main():
         units_warp = pair.final_w * pair.final_h
         scaling = "strong"
     else:
-        pair = config_pair(a.config, seed_offset=rank)
-        res = Resident(pair, dev)
-        units_solve = res.cells * world
+        pair = config_pair(a.config, seed_offset=rank * a.batch)
+        extras = [config_pair(a.config, with_image=False, seed_offset=rank * a.batch + k) for k in range(1, a.batch)]
+        res = Resident(pair, dev, a.batch, extras)
+        units_solve = res.cells * a.batch * world
         units_warp = pair.final_w * pair.final_h * world
         scaling = "weak"
 
@@ -263,7 +276,7 @@ def main():
     kern = {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(["assemble", "eigen", "invert", "lut", "warp"])}
 
     if rank == 0:
-        local_cells = res.cells
+        local_cells = res.cells * getattr(res, "batch", 1)
         flops = K1_FLOPS_PER_CELL_POINT * res.n * local_cells
         t_k1 = kern["assemble"] * 1e-3
         achieved = flops / t_k1 / 1e12
@@ -289,6 +302,7 @@ def main():
             "config": {"workload": f"{a.config}: {CONFIGS[a.config][0]}x{CONFIGS[a.config][1]} pair, "
                                    f"{res.n} correspondences, {res.rows}x{res.cols} mesh, canvas "
                                    f"{pair.final_w}x{pair.final_h}", "mode": a.mode, "variant": a.variant,
+                       "pairs_per_solve_launch": a.batch,
                        "launch": "hip graph replay" if a.graph else "eager",
                        "parallelism": f"{a.mode}x{world}"},
             "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",

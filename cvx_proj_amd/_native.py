@@ -64,6 +64,9 @@ SIGNATURES = {
     "apap_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "apap_solve_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp,
                                     C.c_size_t, _vp]),
+    "apap_solve_batch_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "apap_solve_batch_device": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_double, C.c_double, _vp, _vp,
+                                          C.c_int, _vp, C.c_size_t, _vp]),
     "apap_weights_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp]),
     "apap_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apap_warp_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,

@@ -22,7 +22,7 @@ struct SolvePlan {
     int pts_per_split; // keypoints per slice (a multiple of 4)
     size_t moment_bytes;
 };
-SolvePlan plan_solve(int n, int cells, int variant);
+SolvePlan plan_solve(int n, int cells, int variant, int batch = 1);
 
 constexpr int kMoments = 30;       // distinct sums of A^T W^2 A
 constexpr int kStatusSingular = 1; // bit 0 of the device status word

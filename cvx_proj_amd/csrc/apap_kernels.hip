@@ -24,6 +24,12 @@ namespace {
 using apap::kMoments;
 constexpr int kWave = 64;
 
+// Batched solve: blockIdx.z selects the image pair; element strides between the pairs'
+// arrays (0 = shared by all pairs, e.g. one mesh for a batch of equally sized pairs).
+struct BatchStride {
+    long long table, vertices, moments, denorm, H;
+};
+
 // weight of one keypoint for one cell: max(exp(-|v - s| / sigma^2), gamma), float64 like
 // apap.py:150-152 (np.sqrt and np.exp on float64).
 //
@@ -168,8 +174,12 @@ __device__ __forceinline__ double cell_weight_sq_tab(double vx, double vy, doubl
 __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
                                                        int cells_pad, double gamma2, double inv_sigma2,
-                                                       int pts_per_split, double *__restrict__ moments) {
+                                                       int pts_per_split, double *__restrict__ moments,
+                                                       BatchStride bs) {
     __shared__ double red[3][kMoments][kWave];
+    table += (long long)blockIdx.z * bs.table;
+    vertices += (long long)blockIdx.z * bs.vertices;
+    moments += (long long)blockIdx.z * bs.moments;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cell = blockIdx.x * kWave + lane;
@@ -247,8 +257,12 @@ __device__ __forceinline__ int lds_off(int r, int c) { return r * 256 + ((c ^ ((
 __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
                                                        int cells_pad, double gamma2, double inv_sigma2,
-                                                       int pts_per_split, double *__restrict__ moments) {
+                                                       int pts_per_split, double *__restrict__ moments,
+                                                       BatchStride bs) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
+    table += (long long)blockIdx.z * bs.table;
+    vertices += (long long)blockIdx.z * bs.vertices;
+    moments += (long long)blockIdx.z * bs.moments;
 #if APAP_TABLE_EXP
     __shared__ double s_exp2[64];
     if (threadIdx.x < 64) s_exp2[threadIdx.x] = kExp2Tab[threadIdx.x];  // visible after the first barrier
@@ -532,7 +546,10 @@ template <bool kUseInverseIteration>
 __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
                                                      int cells, int cells_pad,
                                                      const double *__restrict__ denorm, int pick_rank,
-                                                     float *__restrict__ H) {
+                                                     float *__restrict__ H, BatchStride bs) {
+    moments += (long long)blockIdx.z * bs.moments;
+    denorm += (long long)blockIdx.z * bs.denorm;
+    H += (long long)blockIdx.z * bs.H;
     const int cell = blockIdx.x * kWave + threadIdx.x;
     const int cc = min(cell, cells - 1);
     double m[kMoments];
@@ -1032,7 +1049,7 @@ struct ProfScope {
 
 namespace apap {
 
-SolvePlan plan_solve(int n, int cells, int variant) {
+SolvePlan plan_solve(int n, int cells, int variant, int batch) {
     SolvePlan p{};
     if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_MFMA;  // measured faster on C2-C4, DESIGN.md
     p.variant = variant;
@@ -1049,7 +1066,7 @@ SolvePlan plan_solve(int n, int cells, int variant) {
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 4096;
     }();
-    while (splits < 32 && p.cell_tiles * 4 * splits < want_waves && n / (splits * 2) >= 64) splits *= 2;
+    while (splits < 32 && (long long)p.cell_tiles * batch * 4 * splits < want_waves && n / (splits * 2) >= 64) splits *= 2;
     int pps = (n + splits - 1) / splits;
     pps = (pps + 63) / 64 * 64;
     p.splits = (n + pps - 1) / pps;  // no empty split
@@ -1074,48 +1091,66 @@ int apap_set_eigen_solver(int which) {
     return prev;
 }
 
-size_t apap_solve_workspace_bytes(int n, int cells) {
-    if (n < 1 || cells < 1) return 0;
-    // both variants use the same slab geometry; size for the larger split count
-    return apap::plan_solve(n, cells, g_variant).moment_bytes;
+size_t apap_solve_batch_workspace_bytes(int n, int cells, int batch) {
+    if (n < 1 || cells < 1 || batch < 1) return 0;
+    return apap::plan_solve(n, cells, g_variant, batch).moment_bytes * (size_t)batch;
 }
 
-int apap_solve_device(const double *d_table, int n, const double *d_vertices, int cells,
-                      double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
-                      size_t work_bytes, void *stream) {
-    if (!d_table || !d_vertices || !d_denorm || !d_H || !d_work)
+size_t apap_solve_workspace_bytes(int n, int cells) { return apap_solve_batch_workspace_bytes(n, cells, 1); }
+
+int apap_solve_batch_device(const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+                            int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
+                            int batch, void *d_work, size_t work_bytes, void *stream) {
+    if (!d_tables || !d_vertices || !d_denorms || !d_H || !d_work)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: null device pointer");
-    if (n < 1 || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: n=%d cells=%d", n, cells);
-    const apap::SolvePlan p = apap::plan_solve(n, cells, g_variant);
-    if (work_bytes < p.moment_bytes)
-        return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes, p.moment_bytes);
+    if (n < 1 || cells < 1 || batch < 1 || batch > 65535 || vertices_stride < 0)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: n=%d cells=%d batch=%d", n, cells, batch);
+    const apap::SolvePlan p = apap::plan_solve(n, cells, g_variant, batch);
+    if (work_bytes < p.moment_bytes * (size_t)batch)
+        return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes,
+                          p.moment_bytes * (size_t)batch);
     hipStream_t s = (hipStream_t)stream;
     const double inv_sigma = 1.0 / (sigma * sigma);  // apap.py:142
     const double inv_sigma2 = 2.0 * inv_sigma;       // K1 evaluates exp(-2 d / sigma^2) = w^2
     const double gamma2 = gamma > 0.0 ? gamma * gamma : 0.0;
     double *moments = (double *)d_work;
+    BatchStride bs;
+    bs.table = (long long)n * APAP_TABLE_STRIDE;
+    bs.vertices = vertices_stride;
+    bs.moments = (long long)(p.moment_bytes / sizeof(double));
+    bs.denorm = APAP_DENORM_DOUBLES;
+    bs.H = (long long)cells * 9;
     {
-    ProfScope prof(APAP_PROF_ASSEMBLE, s);
-    if (p.variant == APAP_VARIANT_MFMA)
-        hipLaunchKernelGGL(k_assemble_mfma, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
-                           cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments);
-    else
-        hipLaunchKernelGGL(k_assemble_valu, dim3(p.cell_tiles, p.splits), dim3(256), 0, s, d_table, n, d_vertices,
-                           cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments);
+        ProfScope prof(APAP_PROF_ASSEMBLE, s);
+        const dim3 grid(p.cell_tiles, p.splits, batch);
+        if (p.variant == APAP_VARIANT_MFMA)
+            hipLaunchKernelGGL(k_assemble_mfma, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
+                               inv_sigma2, p.pts_per_split, moments, bs);
+        else
+            hipLaunchKernelGGL(k_assemble_valu, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
+                               inv_sigma2, p.pts_per_split, moments, bs);
     }
     const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
     {
         ProfScope prof(APAP_PROF_EIGEN, s);
+        const dim3 grid(p.cell_tiles, 1, batch);
         if (g_eigen == APAP_EIGEN_JACOBI)
-            hipLaunchKernelGGL(k_eigen_denorm<false>, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
-                               p.cells_pad, d_denorm, pick_rank, d_H);
+            hipLaunchKernelGGL(k_eigen_denorm<false>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
+                               pick_rank, d_H, bs);
         else
-            hipLaunchKernelGGL(k_eigen_denorm<true>, dim3(p.cell_tiles), dim3(64), 0, s, moments, p.splits, cells,
-                               p.cells_pad, d_denorm, pick_rank, d_H);
+            hipLaunchKernelGGL(k_eigen_denorm<true>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
+                               pick_rank, d_H, bs);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
     return APAP_OK;
+}
+
+int apap_solve_device(const double *d_table, int n, const double *d_vertices, int cells,
+                      double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
+                      size_t work_bytes, void *stream) {
+    return apap_solve_batch_device(d_table, n, d_vertices, 0, cells, gamma, sigma, d_denorm, d_H, 1, d_work, work_bytes,
+                                   stream);
 }
 
 int apap_weights_device(const double *d_table, int n, const double *d_vertices, int cells,

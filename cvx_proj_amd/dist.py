@@ -72,6 +72,23 @@ def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_be
     return status
 
 
+def hip_solve_batch(tables, denorms, vertices, gamma, sigma):
+    """Several pairs (equal keypoint and cell counts, one shared mesh) in ONE launch:
+    ``tables`` (B, n, 32), ``denorms`` (B, 36), ``vertices`` (cells, 2) -> H (B, cells, 9)."""
+    if not tables.is_cuda:
+        raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_solve_batch needs CUDA/HIP tensors; there is no CPU fallback")
+    batch, n = tables.shape[0], tables.shape[1]
+    cells = vertices.shape[0]
+    H = torch.empty((batch, cells, 9), dtype=torch.float32, device=tables.device)
+    nbytes = max(_native.lib().apap_solve_batch_workspace_bytes(n, cells, batch), 256)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=tables.device)
+    stream = torch.cuda.current_stream(tables.device).cuda_stream
+    _native.check(_native.lib().apap_solve_batch_device(tables.data_ptr(), n, vertices.data_ptr(), 0, cells,
+                                                        float(gamma), float(sigma), denorms.data_ptr(), H.data_ptr(),
+                                                        batch, work.data_ptr(), nbytes, ctypes.c_void_p(stream)))
+    return H
+
+
 class ShardedSolver:
     """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
 
@@ -166,14 +183,24 @@ def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
     H grids in input order (``None`` elsewhere).  All pairs must share one mesh shape."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
-    mine = []
-    for k in range(rank, len(pairs), world):
-        p = pairs[k]
+    mine, tables, dens = [], [], []
+    my_pairs = [pairs[k] for k in range(rank, len(pairs), world)]
+    for p in my_pairs:
         q = _native.host_prepare(p.src, p.dst)
-        table = torch.from_numpy(_native.host_build_table(p.src, q["cf1"], q["cf2"])).to(dev)
-        den = torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])).to(dev)
-        vert = torch.from_numpy(np.ascontiguousarray(p.vertices.reshape(-1, 2))).to(dev)
-        mine.append(solve_fn(table, den, vert, p.gamma, p.sigma))
+        tables.append(torch.from_numpy(_native.host_build_table(p.src, q["cf1"], q["cf2"])))
+        dens.append(torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])))
+    same = (len(my_pairs) > 1 and solve_fn is hip_solve
+            and all(len(p.src) == len(my_pairs[0].src) and np.array_equal(p.vertices, my_pairs[0].vertices)
+                    and (p.gamma, p.sigma) == (my_pairs[0].gamma, my_pairs[0].sigma) for p in my_pairs))
+    if same:   # one batched launch for this rank's pairs
+        vert = torch.from_numpy(np.ascontiguousarray(my_pairs[0].vertices.reshape(-1, 2))).to(dev)
+        Hb = hip_solve_batch(torch.stack(tables).to(dev), torch.stack(dens).to(dev), vert, my_pairs[0].gamma,
+                             my_pairs[0].sigma)
+        mine = list(Hb)
+    else:
+        for p, table, den in zip(my_pairs, tables, dens):
+            vert = torch.from_numpy(np.ascontiguousarray(p.vertices.reshape(-1, 2))).to(dev)
+            mine.append(solve_fn(table.to(dev), den.to(dev), vert, p.gamma, p.sigma))
     if dist is None or world == 1:
         return [h.cpu().numpy().reshape(p.vertices.shape[0], p.vertices.shape[1], 3, 3) for h, p in zip(mine, pairs)]
     per_rank = (len(pairs) + world - 1) // world

@@ -180,6 +180,15 @@ int apap_solve_device(const double *d_table, int n, const double *d_vertices, in
                       double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
                       size_t work_bytes, void *stream);
 
+/* The same for a BATCH of image pairs with equal n and cell count in one launch
+ * (blockIdx.z = pair): d_tables batch x n x 32, d_denorms batch x 36, d_H batch x cells x 9;
+ * d_vertices + k * vertices_stride is pair k's mesh (stride in doubles; 0 = one mesh shared
+ * by all pairs).  Fills the chip with fewer keypoint splits than `batch` separate calls. */
+size_t apap_solve_batch_workspace_bytes(int n, int cells, int batch);
+int apap_solve_batch_device(const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+                            int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
+                            int batch, void *d_work, size_t work_bytes, void *stream);
+
 /* The weights tensor alone: d_W cells x n doubles. */
 int apap_weights_device(const double *d_table, int n, const double *d_vertices, int cells,
                         double gamma, double sigma, double *d_W, void *stream);

@@ -592,3 +592,37 @@ def test_device_entry_points_are_graph_capturable(native, golden):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(res.H, H0) and torch.equal(res.out, out0)
+
+
+def test_batched_solve_equals_separate_solves(native):
+    """apap_solve_batch_device (blockIdx.z = pair) on 5 C5 pairs gives the bits of five
+    separate calls, with a shared mesh and with per-pair meshes."""
+    import ctypes
+    import torch
+    from cvx_proj_amd.dist import hip_solve, hip_solve_batch
+    dev = torch.device("cuda:0")
+    pairs = [config_pair("C5", with_image=False, seed_offset=k) for k in range(5)]
+    tabs, dens = [], []
+    for p in pairs:
+        q = native.host_prepare(p.src, p.dst)
+        tabs.append(torch.from_numpy(native.host_build_table(p.src, q["cf1"], q["cf2"])))
+        dens.append(torch.from_numpy(native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])))
+    vert = torch.from_numpy(pairs[0].vertices.reshape(-1, 2).copy()).to(dev)
+    tables, denorms = torch.stack(tabs).to(dev), torch.stack(dens).to(dev)
+    Hb = hip_solve_batch(tables, denorms, vert, 0.5, 100.0)
+    for k in range(5):
+        Hk = hip_solve(tables[k].contiguous(), denorms[k].contiguous(), vert, 0.5, 100.0)
+        assert torch.equal(Hb[k], Hk), k
+    # per-pair meshes: pair k's vertices shifted by k pixels
+    verts = torch.stack([vert + k for k in range(5)]).contiguous()
+    cells, n = vert.shape[0], tables.shape[1]
+    H2 = torch.empty((5, cells, 9), dtype=torch.float32, device=dev)
+    nbytes = native.lib().apap_solve_batch_workspace_bytes(n, cells, 5)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    native.check(native.lib().apap_solve_batch_device(tables.data_ptr(), n, verts.data_ptr(), cells * 2, cells, 0.5, 100.0,
+                                                      denorms.data_ptr(), H2.data_ptr(), 5, work.data_ptr(), nbytes,
+                                                      ctypes.c_void_p(0)))
+    torch.cuda.synchronize()
+    for k in (0, 3):
+        Hk = hip_solve(tables[k].contiguous(), denorms[k].contiguous(), verts[k].contiguous(), 0.5, 100.0)
+        assert torch.equal(H2[k], Hk), k
