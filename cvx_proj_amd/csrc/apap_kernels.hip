@@ -347,8 +347,9 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
 }
 
 // --------------------------------------------------------------------------------
-// K2: per-cell symmetric 9x9 eigen-solve by cyclic Jacobi sweeps, lanes = cells, the
-// whole problem (45 + 81 doubles) in registers; then the eigenvector of the smallest
+// K2: per-cell symmetric 9x9 eigen-solve, lanes = cells, everything in registers: inverse
+// iteration on an L D L^T factorisation by default, cyclic Jacobi sweeps (45 + 81 doubles)
+// as the fallback and as the selectable alternative; then the eigenvector of the smallest
 // eigenvalue is de-normalised (apap.py:161-168) and stored as float32.
 // --------------------------------------------------------------------------------
 __host__ __device__ constexpr int tri(int i, int j) {
