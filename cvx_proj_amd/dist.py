@@ -132,6 +132,10 @@ class ShardedSolver:
         if d is None or self.world == 1:
             self.H.copy_(mine)
             return self.H
+        if all(rb - ra == b - a for ra, rb in self.parts):
+            # equal shards (e.g. 400 mesh rows over 8 ranks): gather straight into the grid
+            d.all_gather_into_tensor(self.H, mine)
+            return self.H
         self._mine[:(b - a) * self.cols].copy_(mine)
         d.all_gather_into_tensor(self._gather.view(-1, 9), self._mine)
         for r, (ra, rb) in enumerate(self.parts):      # drop the padding of uneven shards
@@ -171,6 +175,9 @@ class ShardedSolver:
             self.status = st
         if d is None or self.world == 1:
             self.out.copy_(self._band[:b - a])
+            return self.out
+        if all(rb - ra == b - a for ra, rb in self.bands):
+            d.all_gather_into_tensor(self.out, self._band[:b - a])
             return self.out
         d.all_gather_into_tensor(self._bands.view(-1, p.final_w, 3), self._band)
         for r, (ra, rb) in enumerate(self.bands):
