@@ -254,7 +254,8 @@ constexpr int kChunk = 64;  // keypoints per LDS buffer
 // 0-15 -> row r, 16-31 -> row r+1) fall on disjoint halves of the 64 banks.
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 256 + ((c ^ ((r & 1) << 4)) << 3); }
 
-__global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict__ table, int n,
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
                                                        int cells_pad, double gamma2, double inv_sigma2,
                                                        int pts_per_split, double *__restrict__ moments,
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
     const int wave = tid >> 6;
     const int kgrp = lane >> 4;  // which of the step's 4 keypoints this lane weighs
     const int col = lane & 15;   // cell within the wave's 16 (A operand) / table column (B operand)
-    const int cell = blockIdx.x * 64 + wave * 16 + col;
+    const int cell = blockIdx.x * (16 * kWaves) + wave * 16 + col;
     const int cc = min(cell, cells - 1);
     const double vx = vertices[2 * cc];
     const double vy = vertices[2 * cc + 1];
@@ -282,11 +283,13 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
 
     // staging: thread t moves 16-byte pieces t, t+256, t+512, t+768 of a chunk;
     // piece q = (row q >> 4, 16-byte slot q & 15)
-    double2 stage[4];
+    constexpr int kThreads = kWaves * 64;
+    constexpr int kPieces = kChunk * 16 / kThreads;  // 16-byte pieces of a chunk per thread
+    double2 stage[kPieces];
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i;
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = tid + kThreads * i;
             const int p = p_begin + c * kChunk + (q >> 4);
             stage[i] = (p < p_end) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
                                    : make_double2(0.0, 0.0);  // zero rows add nothing whatever their weight
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
     };
     auto store_chunk = [&](int b) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = tid + 256 * i;
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = tid + kThreads * i;
             const int r = q >> 4;
             const int slot = (q & 15) ^ ((r & 1) << 3);
             *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[i];
@@ -337,12 +340,14 @@ __global__ __launch_bounds__(256) void k_assemble_mfma(const double *__restrict_
     // D layout of v_mfma_f64_16x16x4_f64: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15],
     // row = cell within the wave's 16, col = moment index (acc0: 0..15, acc1: 16..31).
     double *slab = moments + (size_t)blockIdx.y * kMoments * cells_pad;
-    const int cell_base = blockIdx.x * 64 + wave * 16 + kgrp;
+    const int cell_base = blockIdx.x * (16 * kWaves) + wave * 16 + kgrp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ci = cell_base + 4 * i;
-        slab[(size_t)col * cells_pad + ci] = acc0[i];
-        if (col < kMoments - 16) slab[(size_t)(16 + col) * cells_pad + ci] = acc1[i];
+        if (ci < cells_pad) {  // an 8-wave block may overhang the padded cell count
+            slab[(size_t)col * cells_pad + ci] = acc0[i];
+            if (col < kMoments - 16) slab[(size_t)(16 + col) * cells_pad + ci] = acc1[i];
+        }
     }
 }
 
@@ -1124,8 +1129,9 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
     {
         ProfScope prof(APAP_PROF_ASSEMBLE, s);
         const dim3 grid(p.cell_tiles, p.splits, batch);
+        // 4 waves (64 cells) per block measured best: 2 -> 224 us, 4 -> 201 us, 8 -> 227 us at C3
         if (p.variant == APAP_VARIANT_MFMA)
-            hipLaunchKernelGGL(k_assemble_mfma, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
+            hipLaunchKernelGGL(k_assemble_mfma<4>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
                                inv_sigma2, p.pts_per_split, moments, bs);
         else
             hipLaunchKernelGGL(k_assemble_valu, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
