@@ -247,7 +247,14 @@ __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict_
 // buffered, register-staged so the next chunk's global loads fly during the MFMAs).
 // --------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
-constexpr int kChunk = 64;  // keypoints per LDS buffer
+// Keypoints per LDS buffer (16 KiB).  32 / 48 / 64 measured the same (196-200 us at C3): the
+// kernel is bound by the fp64 pipe, not by barriers or occupancy (VGPR + AGPR = 102 -> 4 waves
+// per SIMD; forcing <= 96 registers for 5-6 waves per SIMD changed nothing either).
+#ifndef APAP_K1_CHUNK
+#define APAP_K1_CHUNK 64
+#endif
+constexpr int kChunk = APAP_K1_CHUNK;
+static_assert(kChunk % 16 == 0 && kChunk % 4 == 0, "chunk must split evenly over 256 threads and 4-keypoint steps");
 
 // Byte offset of table entry (row r, column c) in an LDS chunk: 256-B rows; odd rows swap
 // their 128-B halves so that the two keypoint rows a 32-lane ds_read_b64 covers (lanes
@@ -1064,7 +1071,7 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch) {
     // Fill the chip (256 CUs x 4 SIMDs): aim at >= 4 waves per SIMD (also evens out the
     // blocks-per-CU imbalance: 2500 waves leave SIMDs with 2 or 3, 5000 with 4 or 5).  Small meshes split
     // the keypoint list over grid.y; each split writes its own moment slab and K2 adds
-    // the slabs in a fixed order.  A split is at least one 64-keypoint LDS chunk and a whole
+    // the slabs in a fixed order.  A split is at least one LDS chunk of keypoints and a whole
     // number of chunks (a partial chunk costs as much as a full one in the MFMA kernel).
     int splits = 1;
     static const int want_waves = [] {
@@ -1072,9 +1079,9 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch) {
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 4096;
     }();
-    while (splits < 32 && (long long)p.cell_tiles * batch * 4 * splits < want_waves && n / (splits * 2) >= 64) splits *= 2;
+    while (splits < 32 && (long long)p.cell_tiles * batch * 4 * splits < want_waves && n / (splits * 2) >= kChunk) splits *= 2;
     int pps = (n + splits - 1) / splits;
-    pps = (pps + 63) / 64 * 64;
+    pps = (pps + kChunk - 1) / kChunk * kChunk;
     p.splits = (n + pps - 1) / pps;  // no empty split
     p.pts_per_split = pps;
     p.moment_bytes = (size_t)p.splits * kMoments * p.cells_pad * sizeof(double);
