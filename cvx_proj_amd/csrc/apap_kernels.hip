@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         if (c + 1 < nchunks) load_chunk(c + 1);
         const unsigned char *buf = lds[c & 1];
         // a partial last chunk runs all 16 steps: its missing rows are zero
-#pragma unroll 4
+#pragma unroll  // all 16 steps: LDS addresses become immediates (-3 % vs unroll 4)
         for (int s = 0; s < kChunk / 4; ++s) {
             const int r = 4 * s + kgrp;
             const double2 xy = *reinterpret_cast<const double2 *>(buf + lds_off(r, 30));
