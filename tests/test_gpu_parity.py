@@ -98,13 +98,16 @@ def test_ragged_shapes_vs_oracle(native, variant, rows, cols, n):
         assert d.max() < 1e-3
 
 
-def test_all_weights_clamped(native, variant):
+@pytest.mark.parametrize("sigma", [0.5, 1e-3, 1e-160])
+def test_all_weights_clamped(native, variant, sigma):
     """sigma so small that every weight is gamma: all cells get the same (global DLT)
-    homography."""
+    homography.  1e-3 drives the scaled exponent past 2^31 (the range reduction's integer
+    conversion must saturate), 1e-160 makes 1 / sigma^2 infinite."""
     p = synth_pair(640, 480, 200, 6, seed=5)
-    H, W = native.local_homography(p.src, p.dst, p.vertices, 0.5, 0.5)
+    H, W = native.local_homography(p.src, p.dst, p.vertices, 0.5, sigma)
     assert (W == 0.5).all()
-    H_ref, _ = O.local_homography_loop(p.src, p.dst, p.vertices, 0.5, 0.5, want_weights=False)
+    with np.errstate(all="ignore"):
+        H_ref, _ = O.local_homography_loop(p.src, p.dst, p.vertices, 0.5, sigma, want_weights=False)
     assert O.reprojection_rmse_delta(H, H_ref, p.src).max() < RMSE_BAR
     assert O.reprojection_rmse_delta(H, np.broadcast_to(H[0, 0], H.shape), p.src).max() < 1e-9
 
