@@ -289,7 +289,7 @@ def main():
         if os.path.exists(tfile):
             tj = json.load(open(tfile))
             traffic = tj.get(f"{a.config}:k_assemble_{resolved}")
-            traffic_warp = tj.get(f"{a.config}:k_warp")
+            traffic_warp = tj.get(f"{a.config}:k_warp_rows", tj.get(f"{a.config}:k_warp"))
         # K3 (HBM-bound half of the metric): 6 B per in-range pixel, 3 B per blank one
         out_pixels = pair.final_w * pair.final_h
         nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu()) if a.mode == "pairs" or world == 1 else None
@@ -320,9 +320,9 @@ def main():
                          "note": "fp64 FMA work: the f64 matrix and vector pipes share one 78.6 TF datasheet "
                                  "rate (54-59 TF sustained, profiles/r01_peak_fp64.txt); algorithmic 58 flop per "
                                  "(cell, keypoint) counts sqrt and exp as one flop each, the kernel executes "
-                                 "~128 flop-slots for them (DESIGN.md section 3)"},
+                                 "~89 flops per pair for those 58 (DESIGN.md section 3)"},
             "roofline_warp": None if warp_bytes is None else {
-                "kernel": "k_warp", "bound": "hbm", "achieved": warp_bytes / (kern["warp"] * 1e-3) / 1e9,
+                "kernel": "k_warp_rows", "bound": "hbm", "achieved": warp_bytes / (kern["warp"] * 1e-3) / 1e9,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (kern["warp"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "traffic": traffic_warp},
         }

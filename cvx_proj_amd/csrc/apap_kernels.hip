@@ -971,7 +971,8 @@ __device__ __forceinline__ void target_of(const double *__restrict__ hinv_pad, i
     target_from(load_hinv(hinv_pad, (unsigned)cell), x, y, tx, ty);
 }
 
-// K3: backward warp.  One thread = 4 consecutive canvas pixels in flat order = 12
+// K3, flat-order form (fallback for sources with a side of 2^24 pixels or more, and the
+// baseline of the strip form below).  One thread = 4 consecutive canvas pixels in flat order = 12
 // contiguous output bytes = one global_store_dwordx3; a wave writes 768 contiguous
 // bytes.  The gather reads 3 bytes per pixel with one unaligned dword load; neighbouring
 // lanes read neighbouring source pixels because local homographies are close to the
@@ -1080,6 +1081,159 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
             o[3 * k] = (uint8_t)(px[k] & 0xff);
             o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
             o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
+        }
+    }
+}
+
+// K3, row-strip form.  Mesh cells are small (C3: ~20 x 11 pixels), so the flat-order kernel
+// above fetches two 72-byte matrices for every 12 bytes it writes.  Here a lane owns 4
+// consecutive pixels of a row and walks kRows consecutive rows with them; the wave shares the
+// row, so the row's cell lookup is a scalar load, the lane's four column lookups are done once,
+// and the matrices are re-fetched only when the strip crosses into the next cell row (a
+// wave-uniform branch).  Same arithmetic per pixel, same bytes written.
+// What a lane keeps per pixel while its strip stays in one cell row: the three products with
+// the pixel's x (the first terms of the reference's sums, apap.py:172-184) and the other six
+// coefficients.
+struct PixelH {
+    double p0, p1, p2;  // h0 x, h3 x, h6 x
+    double h1, h2, h4, h5, h7, h8;
+};
+
+__device__ __forceinline__ PixelH pixel_h(const Hinv9 &h, double x) {
+    PixelH q;
+    q.p0 = h.a.x * x; q.p1 = h.b.y * x; q.p2 = h.d.x * x;
+    q.h1 = h.a.y; q.h2 = h.b.x; q.h4 = h.c.x; q.h5 = h.c.y; q.h7 = h.d.y; q.h8 = h.e.x;
+    return q;
+}
+
+template <bool kBlend, int kRows>
+__global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ img, int img_h, int img_w,
+                                                   const double *__restrict__ hinv_pad, int mesh_cols,
+                                                   const int *__restrict__ lut, int final_w, int final_h,
+                                                   int off_x, int off_y, uint8_t *__restrict__ out,
+                                                   const uint8_t *__restrict__ center, int center_h, int center_w,
+                                                   int row_begin, int row_count) {
+    // (Renumbering the blocks so that each XCD owns a band of rows was measured: no change.)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
+    const int y_first = row_begin + ((int)blockIdx.y * 4 + wave) * kRows;
+    const int y_end = min(y_first + kRows, row_begin + row_count);
+    if (j0 >= final_w || y_first >= y_end) return;
+    const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
+    const unsigned clast = kBlend ? (unsigned)center_h * (unsigned)center_w * 3u - 4u : 0u;
+    const int npx = min(4, final_w - j0);
+    int col[4];
+    double xs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = min(j0 + k, final_w - 1);  // pixels past the row end repeat the last one and are not stored
+        col[k] = lut[(unsigned)(final_h + j)];
+        xs[k] = (double)(j - off_x);
+    }
+    // Staged over the whole strip so that a lane has its kRows x 4 gathers in flight at once
+    // instead of a lookup -> matrices -> arithmetic -> gather -> store chain per row.
+    int rr[kRows];
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) rr[t] = lut[(unsigned)min(y_first + t, y_end - 1)];
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) rr[t] = __builtin_amdgcn_readfirstlane(rr[t]);
+    unsigned off[kRows][4];
+    unsigned okbits = 0u;
+    // One pass per cell row the strip touches (usually one, two when it crosses an edge): fetch
+    // that row's matrices, then do every strip row that lies in it.  All branches are wave-uniform.
+    unsigned todo = (1u << kRows) - 1u;
+    while (todo != 0u) {
+        const int first = __builtin_ctz(todo);
+        int r = rr[0];
+#pragma unroll
+        for (int t = 1; t < kRows; ++t) r = (t == first) ? rr[t] : r;
+        const int base = r * mesh_cols;
+        const Hinv9 ha = load_hinv(hinv_pad, (unsigned)(base + col[0]));
+        const Hinv9 hb = load_hinv(hinv_pad, (unsigned)(base + col[3]));
+        PixelH q[4];
+        q[0] = pixel_h(ha, xs[0]);
+        q[3] = pixel_h(hb, xs[3]);
+#pragma unroll
+        for (int k = 1; k < 3; ++k) {
+            const bool is_a = col[k] == col[0];
+            Hinv9 hk = select_hinv(is_a, ha, hb);
+            if (!is_a && col[k] != col[3]) hk = load_hinv(hinv_pad, (unsigned)(base + col[k]));  // a third cell
+            q[k] = pixel_h(hk, xs[k]);
+        }
+#pragma unroll
+        for (int t = 0; t < kRows; ++t) {
+            if (rr[t] != r) continue;
+            todo &= ~(1u << t);
+            const double yd = (double)(y_first + t - off_y);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // (h0 x + h1 y) + h2 and so on: the order of the reference's matrix-vector product
+                const double t0 = fma(q[k].h1, yd, q[k].p0) + q[k].h2;
+                const double t1 = fma(q[k].h4, yd, q[k].p1) + q[k].h5;
+                const double t2 = fma(q[k].h7, yd, q[k].p2) + q[k].h8;
+                // shared reciprocal (one Newton step: ~2^-46) and a residual correction per
+                // quotient: the quotient's error before its final rounding is ~2^-92
+                double rc = __builtin_amdgcn_rcp(t2);
+                rc = fma(fma(-t2, rc, 1.0), rc, rc);
+                const double q0 = t0 * rc, q1 = t1 * rc;
+                const double tx = fma(fma(-t2, q0, t0), rc, q0);
+                const double ty = fma(fma(-t2, q1, t1), rc, q1);
+                // strict 0 < t < size, then truncation (apap.py:214-215).  For t > 0 the upper
+                // test is the same on the truncated integer (the conversion saturates, NaN
+                // fails t > 0).
+                const int ix = (int)tx, iy = (int)ty;
+                const bool ok = (tx > 0.0) & (ty > 0.0) & (ix < img_w) & (iy < img_h);  // no short-circuit branches
+                okbits |= ok ? (1u << (4 * t + k)) : 0u;
+                off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0u;
+            }
+        }
+    }
+    unsigned int px[kRows][4];
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned int v;
+            const unsigned oc = off[t][k] < last ? off[t][k] : last;
+            __builtin_memcpy(&v, img + oc, 4);
+            v >>= 8 * (off[t][k] - oc);
+            px[t][k] = ((okbits >> (4 * t + k)) & 1u) ? (v & 0x00ffffffu) : 0u;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) {
+        const int y = y_first + t;
+        if (y >= y_end) break;  // wave-uniform
+        if (kBlend) {
+            const int ci = y - off_y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cj = j0 + k - off_x;
+                const bool in = ci >= 0 && ci < center_h && cj >= 0 && cj < center_w;
+                const unsigned co = in ? ((unsigned)ci * (unsigned)center_w + (unsigned)cj) * 3u : 0u;
+                const unsigned cc = co < clast ? co : clast;
+                unsigned int c;
+                __builtin_memcpy(&c, center + cc, 4);
+                c = in ? ((c >> (8 * (co - cc))) & 0x00ffffffu) : 0u;
+                const unsigned w = px[t][k];
+                const unsigned avg = (w & c) + (((w ^ c) & 0x00fefefeu) >> 1);
+                px[t][k] = (w != 0u && c != 0u) ? avg : (w | c);
+            }
+        }
+        uint8_t *o = out + ((size_t)(y - row_begin) * (size_t)final_w) * 3 + (unsigned)j0 * 3u;
+        if (npx == 4) {
+            Bytes12 v;
+            v.a = px[t][0] | (px[t][1] << 24);
+            v.b = (px[t][1] >> 8) | (px[t][2] << 16);
+            v.c = (px[t][2] >> 16) | (px[t][3] << 8);
+            __builtin_memcpy(o, &v, 12);  // rows start at any byte: an unaligned 12-byte store
+        } else {
+            for (int k = 0; k < npx; ++k) {
+                o[3 * k] = (uint8_t)(px[t][k] & 0xff);
+                o[3 * k + 1] = (uint8_t)((px[t][k] >> 8) & 0xff);
+                o[3 * k + 2] = (uint8_t)((px[t][k] >> 16) & 0xff);
+            }
         }
     }
 }
@@ -1374,7 +1528,32 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
     if (row_count == 0) return APAP_OK;  // an empty band: only the set-up kernel ran
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
-    {
+    // APAP_WARP_KERNEL (experiments): 0 = flat-order kernel, n = row strips of n rows per wave.
+    // Default 4: 3 / 4 / 5 / 6 measured within 2 % of each other at C3, 2 and 8 are 8-10 % slower.
+    static const int warp_kernel = getenv("APAP_WARP_KERNEL") ? atoi(getenv("APAP_WARP_KERNEL")) : 4;
+    // the strip kernel forms source offsets with 24-bit multiplies
+    if (warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24)) {
+        ProfScope prof(APAP_PROF_WARP, s);
+        const int rows = warp_kernel;  // rows per wave
+        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
+#define APAP_LAUNCH_ROWS(R)                                                                                          \
+    if (d_center)                                                                                                    \
+        hipLaunchKernelGGL((k_warp_rows<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols,  \
+                           lut, final_w, final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin,      \
+                           row_count);                                                                                    \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_warp_rows<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, \
+                           lut, final_w, final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin,    \
+                           row_count)
+        if (rows == 4) { APAP_LAUNCH_ROWS(4); }
+        else if (rows == 3) { APAP_LAUNCH_ROWS(3); }
+        else if (rows == 5) { APAP_LAUNCH_ROWS(5); }
+        else if (rows == 6) { APAP_LAUNCH_ROWS(6); }
+        else if (rows == 8) { APAP_LAUNCH_ROWS(8); }
+        else if (rows == 16) { APAP_LAUNCH_ROWS(16); }
+        else { APAP_LAUNCH_ROWS(2); }
+#undef APAP_LAUNCH_ROWS
+    } else {
         ProfScope prof(APAP_PROF_WARP, s);
         const dim3 grid((unsigned)((threads + 255) / 256));
         if (d_center)

@@ -11,6 +11,10 @@ out = sys.argv[1]
 
 
 def short(name):
+    if "k_warp_rows<true" in name or "k_warp_rowsILb1E" in name:
+        return "k_warp_rows<stitch>"
+    if "k_warp_rows" in name:
+        return "k_warp_rows"
     if "k_warp<true>" in name or "k_warpILb1E" in name:
         return "k_warp<stitch>"
     for k in ("k_assemble_valu", "k_assemble_mfma", "k_eigen_denorm", "k_invert_cells", "k_cell_lut", "k_warp_coords",
