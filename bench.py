@@ -100,6 +100,16 @@ class Resident:
                                          self.out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
                                          self.status.data_ptr(), ctypes.c_void_p(stream)))
 
+    def equalize(self, stream):
+        """Per-channel histogram equalisation of the source image (the pre-processing of
+        apap.py:236-237); timed as an extra, not part of ``value``."""
+        p = self.pair
+        if not hasattr(self, "eq_out"):
+            self.eq_out = torch.empty_like(self.img)
+            self.eq_work = torch.zeros(N.lib().apap_equalize_workspace_bytes(3), dtype=torch.uint8, device=self.img.device)
+        N.check(N.lib().apap_equalize_hist_device(self.img.data_ptr(), p.shape[0], p.shape[1], 3, self.eq_out.data_ptr(),
+                                                  self.eq_work.data_ptr(), self.eq_work.numel(), ctypes.c_void_p(stream)))
+
     def stitch(self, stream):
         """Fused warp + paste + uniform_blend (the reference's commented-out tail,
         apap.py:258-262); timed as an extra, not part of ``value``."""
@@ -263,17 +273,29 @@ def main():
         res.warp(stream)            # leave the plain warped canvas in res.out for the byte count below
         torch.cuda.synchronize()
 
+    t_eq = None
+    if hasattr(res, "equalize"):    # extra: the pre-processing of both images is one call each
+        res.equalize(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            res.equalize(stream)
+        torch.cuda.synchronize()
+        t_eq = time.perf_counter() - t0
+
     # per-kernel durations, HIP events on the launch stream (rank-local)
     N.lib().apap_profile_enable(1)
     for _ in range(a.steps):
         res.solve(stream)
         res.warp(stream)
+        if t_eq is not None:
+            res.equalize(stream)
     torch.cuda.synchronize()
-    ms = (ctypes.c_float * 5)()
-    cnt = (ctypes.c_int * 5)()
+    ms = (ctypes.c_float * N.PROF_SLOTS)()
+    cnt = (ctypes.c_int * N.PROF_SLOTS)()
     N.check(N.lib().apap_profile_read(ms, cnt))
     N.lib().apap_profile_enable(0)
-    kern = {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(["assemble", "eigen", "invert", "lut", "warp"])}
+    kern = {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(N.PROF_NAMES) if cnt[i] or i < 5}
 
     if rank == 0:
         local_cells = res.cells * getattr(res, "batch", 1)
@@ -312,6 +334,15 @@ def main():
                 "value": pair.final_w * pair.final_h * a.steps / t_stitch / 1e6, "unit": "Mpix/s (rank 0)",
                 "ms_per_step": t_stitch / a.steps * 1e3,
                 "note": "fused warp + paste + uniform_blend, apap.py:258-262; extra, not in `value`"},
+            "equalize": None if t_eq is None else {
+                "value": pair.shape[0] * pair.shape[1] * a.steps / t_eq / 1e6, "unit": "Mpix/s (rank 0)",
+                "ms_per_step": t_eq / a.steps * 1e3,
+                "roofline": {"kernels": "k_eq_hist + k_eq_apply", "bound": "hbm",
+                             "achieved": 3.0 * pair.img.size / ((kern["eq_hist"] + kern["eq_apply"]) * 1e-3) / 1e9,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": 3.0 * pair.img.size / ((kern["eq_hist"] + kern["eq_apply"]) * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                "note": "per-channel cv.equalizeHist of the 4K source image, utils.py:85-91; algorithmic "
+                        "traffic 3 bytes per image byte (read, read, write); extra, not in `value`"},
             "kernels_ms": kern,
             "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",

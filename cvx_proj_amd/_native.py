@@ -17,6 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
+# kernel slots of apap_profile_read (include/apap_hip.h)
+PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply", "ransac")
+PROF_SLOTS = len(PROF_NAMES)
 TABLE_STRIDE = 32
 DENORM_DOUBLES = 36
 VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA = 0, 1, 2
@@ -80,6 +83,9 @@ SIGNATURES = {
                                           C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp]),
     "apap_flatten_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "apap_blend_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "apap_equalize_hist": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
+    "apap_equalize_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "apap_equalize_hist_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
 }
 
 _lib = None
@@ -260,4 +266,15 @@ def uniform_blend(img1, img2, device=-1):
     out = np.empty_like(a)
     check(lib().apap_uniform_blend(_ptr(a, C.c_uint8), _ptr(b, C.c_uint8), a.shape[0], a.shape[1],
                                    _ptr(out, C.c_uint8), device))
+    return out
+
+
+def equalize_hist(img, device=-1):
+    """Per-channel ``cv.equalizeHist`` of an (h, w) or (h, w, c) uint8 image, c <= 4."""
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    if a.ndim not in (2, 3) or (a.ndim == 3 and not 1 <= a.shape[2] <= 4) or a.size == 0:
+        raise ValueError(f"image must be (h, w) or (h, w, 1..4) uint8 and non-empty; got {a.shape}")
+    channels = 1 if a.ndim == 2 else a.shape[2]
+    out = np.empty_like(a)
+    check(lib().apap_equalize_hist(_ptr(a, C.c_uint8), a.shape[0], a.shape[1], channels, _ptr(out, C.c_uint8), device))
     return out

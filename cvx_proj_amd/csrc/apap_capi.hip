@@ -301,4 +301,26 @@ int apap_uniform_blend(const uint8_t *img1, const uint8_t *img2, int h, int w, u
     return APAP_OK;
 }
 
+int apap_equalize_hist(const uint8_t *img, int h, int w, int channels, uint8_t *out, int device) {
+    if (!img || !out || h < 1 || w < 1 || channels < 1 || channels > 4)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_equalize_hist: bad argument");
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev;
+    int rc = select_device(device, &dev);
+    if (rc) return rc;
+    const size_t bytes = (size_t)h * w * channels;
+    const size_t work_bytes = apap_equalize_workspace_bytes(channels);
+    void *d_a, *d_o, *d_work;
+    if ((rc = slot_get(S_IMG, bytes, dev, &d_a))) return rc;
+    if ((rc = slot_get(S_OUT, bytes, dev, &d_o))) return rc;
+    if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(d_a, img, bytes, hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemsetAsync(d_work, 0, work_bytes, nullptr));  // the pooled buffer is shared: zero it per call
+    rc = apap_equalize_hist_device((const uint8_t *)d_a, h, w, channels, (uint8_t *)d_o, d_work, work_bytes, nullptr);
+    if (rc) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(out, d_o, bytes, hipMemcpyDeviceToHost, nullptr));
+    APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    return APAP_OK;
+}
+
 }  // extern "C"

@@ -10,6 +10,23 @@ namespace apap {
 // Records a thread-local message for apap_last_error() and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Records "<what>: <hipGetErrorString>" and returns APAP_ERR_HIP.
+int hip_fail(int hip_error, const char *what);
+
+// Optional per-kernel timing (apap_profile_enable / apap_profile_read): brackets the kernels
+// launched in its scope with HIP events on `stream`.
+struct ProfScope {
+    ProfScope(int slot, void *stream);
+    ~ProfScope();
+    ProfScope(const ProfScope &) = delete;
+    ProfScope &operator=(const ProfScope &) = delete;
+
+  private:
+    void *stream_, *a_, *b_;
+    int slot_;
+    bool on_;
+};
+
 bool inv3_f64(const double in[9], double out[9]);
 bool inv3_f32(const float in[9], float out[9]);
 

@@ -1293,9 +1293,8 @@ __global__ __launch_bounds__(256) void k_blend(const uint8_t *__restrict__ a, co
     }
 }
 
-inline int hip_fail(hipError_t e, const char *what) {
-    return apap::fail(APAP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
-}
+inline int hip_fail(hipError_t e, const char *what) { return apap::hip_fail((int)e, what); }
+using apap::ProfScope;
 
 int g_variant = APAP_VARIANT_AUTO;
 int g_eigen = APAP_EIGEN_AUTO;
@@ -1308,26 +1307,29 @@ struct ProfSpan {
 bool g_prof_on = false;
 std::vector<ProfSpan> g_prof;
 
-struct ProfScope {
-    hipStream_t s;
-    ProfSpan span;
-    bool on;
-    ProfScope(int slot, hipStream_t stream) : s(stream), on(g_prof_on) {
-        if (!on) return;
-        span.slot = slot;
-        on = hipEventCreate(&span.a) == hipSuccess && hipEventCreate(&span.b) == hipSuccess;
-        if (on) (void)hipEventRecord(span.a, s);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        (void)hipEventRecord(span.b, s);
-        g_prof.push_back(span);
-    }
-};
-
 }  // namespace
 
 namespace apap {
+
+int hip_fail(int hip_error, const char *what) {
+    return fail(APAP_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)hip_error));
+}
+
+ProfScope::ProfScope(int slot, void *stream) : stream_(stream), a_(nullptr), b_(nullptr), slot_(slot), on_(g_prof_on) {
+    if (!on_) return;
+    hipEvent_t a, b;
+    on_ = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+    if (!on_) return;
+    a_ = a;
+    b_ = b;
+    (void)hipEventRecord(a, (hipStream_t)stream_);
+}
+
+ProfScope::~ProfScope() {
+    if (!on_) return;
+    (void)hipEventRecord((hipEvent_t)b_, (hipStream_t)stream_);
+    g_prof.push_back(ProfSpan{slot_, (hipEvent_t)a_, (hipEvent_t)b_});
+}
 
 SolvePlan plan_solve(int n, int cells, int variant, int batch) {
     SolvePlan p{};

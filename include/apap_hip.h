@@ -68,7 +68,10 @@ extern "C" {
 #define APAP_PROF_INVERT 2   /* per-cell 3x3 inverse                    */
 #define APAP_PROF_LUT 3      /* canvas row/column -> cell lookup table  */
 #define APAP_PROF_WARP 4     /* K3: backward warp gather                */
-#define APAP_PROF_SLOTS 5
+#define APAP_PROF_EQ_HIST 5  /* E1: per-channel histogram               */
+#define APAP_PROF_EQ_APPLY 6 /* E2: table rebuild + mapping             */
+#define APAP_PROF_RANSAC 7   /* R1-R3: hypotheses, scoring, selection   */
+#define APAP_PROF_SLOTS 8
 
 /* ---------------------------------------------------------------- diagnostics --- */
 const char *apap_last_error(void);
@@ -228,6 +231,21 @@ int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, c
 int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_status, void *stream);
 
 int apap_blend_device(const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream);
+
+/* ------------------------------------------- callers of the path --- */
+/* Pre-processing of apap.py:236-237 = utils.py:85-91 visualize_equalized_hist:
+ *   np.stack([cv.equalizeHist(img[..., i]) for i in range(3)], axis=-1)
+ * on an interleaved uint8 image of 1..4 channels (h x w x channels); out may alias nothing.
+ * cv::equalizeHist (opencv-python 4.6.0.66, absent from this image) is restated from its
+ * published algorithm: see oracle/frontend_oracle.py. */
+int apap_equalize_hist(const uint8_t *img, int h, int w, int channels, uint8_t *out, int device);
+size_t apap_equalize_workspace_bytes(int channels);
+/* Resident-data form: three kernels on `stream` (histogram; table; mapping).  WORKSPACE
+ * CONTRACT: d_work (16-byte aligned, apap_equalize_workspace_bytes(channels) bytes) must be all
+ * zero on entry - zero it once after allocating it - and is all zero again, apart from the table
+ * at its end, when the call's kernels have run; so back-to-back calls need no memset. */
+int apap_equalize_hist_device(const uint8_t *d_img, int h, int w, int channels, uint8_t *d_out, void *d_work,
+                              size_t work_bytes, void *stream);
 
 #ifdef __cplusplus
 }
