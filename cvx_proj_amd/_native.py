@@ -86,6 +86,11 @@ SIGNATURES = {
     "apap_equalize_hist": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "apap_equalize_workspace_bytes": (C.c_size_t, [C.c_int]),
     "apap_equalize_hist_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "apap_find_homography_ransac": (C.c_int, [_f32p, _f32p, C.c_int, C.c_double, C.c_int, C.c_ulonglong, _f64p, _u8p,
+                                              _i32p, C.c_int]),
+    "apap_ransac_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "apap_ransac_device": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_int, C.c_ulonglong, _vp, _vp, _vp, _vp,
+                                     C.c_size_t, _vp]),
 }
 
 _lib = None
@@ -278,3 +283,24 @@ def equalize_hist(img, device=-1):
     out = np.empty_like(a)
     check(lib().apap_equalize_hist(_ptr(a, C.c_uint8), a.shape[0], a.shape[1], channels, _ptr(out, C.c_uint8), device))
     return out
+
+
+RANSAC_ITERATIONS = 2048                 # include/apap_hip.h
+RANSAC_SEED = 0x5EEDC0DE5EEDC0DE
+
+
+def find_homography_ransac(src, dst, thresh=5.0, iterations=RANSAC_ITERATIONS, seed=RANSAC_SEED, device=-1):
+    """``cv.findHomography(src, dst, cv.RANSAC, thresh)``: ``(H (3, 3) float64 or None, mask (n, 1) uint8)``."""
+    s = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(dst, dtype=np.float32).reshape(-1, 2)
+    if s.shape != d.shape:
+        raise ValueError(f"src and dst must have the same number of points; got {s.shape} and {d.shape}")
+    H = np.zeros(9, dtype=np.float64)
+    mask = np.zeros(len(s), dtype=np.uint8)
+    inliers = C.c_int(0)
+    check(lib().apap_find_homography_ransac(_ptr(s, C.c_float), _ptr(d, C.c_float), len(s), float(thresh), int(iterations),
+                                            C.c_ulonglong(seed), _ptr(H, C.c_double), _ptr(mask, C.c_uint8),
+                                            C.byref(inliers), device))
+    if inliers.value < 4:
+        return None, mask.reshape(-1, 1)
+    return H.reshape(3, 3), mask.reshape(-1, 1)

@@ -10,7 +10,7 @@ Command line (reference apap.py:220-265 takes ``[case_idx] [img_idx]`` and reads
 dataset that is not distributed; the positional arguments and the output file are kept,
 the inputs come from ``--pair``)::
 
-    python -m cvx_proj_amd.apap [case_idx] [img_idx] [--pair pair.npz | --synth C1]
+    python -m cvx_proj_amd.apap [case_idx] [img_idx] [--data-root DIR | --pair pair.npz | --synth C1]
                                 [--config configs/case1.txt] [--out-prefix ../diff_1/results/]
                                 [--mesh-size 100] [--gamma 0.5] [--sigma 100] [--warp out.npy | --stitch out.npy]
 """
@@ -186,6 +186,9 @@ def main(argv=None):
     ap.add_argument("img_idx", nargs="?", type=int, default=1)
     ap.add_argument("--pair", help=".npz with src, dst (n,2), H (3,3), other_shape, center_shape[, other_img]")
     ap.add_argument("--synth", help="use a synthetic configuration of cvx_proj_amd.synth (C1..C5)")
+    ap.add_argument("--data-root", help="the reference's own flow (apap.py:236-238): read case{c}/scat/img_haze{i}.png and "
+                                        "case{c}/keypoints.mat under this directory (the reference's is ../diff_1/raw_data), "
+                                        "equalise, RANSAC seed homography, then the hot path")
     ap.add_argument("--config", help="key = value file; mesh_size / gamma / sigma are read")
     ap.add_argument("--mesh-size", type=int)
     ap.add_argument("--gamma", type=float)
@@ -214,6 +217,19 @@ def main(argv=None):
         other_shape, center_shape = tuple(z["other_shape"]), tuple(z["center_shape"])
         other_img = z["other_img"] if ((a.warp or a.stitch) and "other_img" in z) else None
         center_img = z["center_img"] if (a.stitch and "center_img" in z) else None
+    elif a.data_root:
+        from .baseline_stitch_test import CENTER_PIC_ID, visualize_feature_pairs
+        from .utils import get_no_scat_img, visualize_equalized_hist
+        center_eq = visualize_equalized_hist(a.case_idx, CENTER_PIC_ID, root=a.data_root, device=a.device)
+        other_eq = visualize_equalized_hist(a.case_idx, a.img_idx, root=a.data_root, device=a.device)
+        src, dst, Hg = visualize_feature_pairs(center_eq, other_eq, case_idx=a.case_idx, pic_id=a.img_idx, swap=True,
+                                               root=a.data_root, device=a.device)
+        other_shape, center_shape = other_eq.shape, center_eq.shape
+        other_img = center_img = None
+        if a.warp or a.stitch:      # the blend uses the haze-free pictures (apap.py:245,258-262)
+            center_img, other_img = get_no_scat_img(a.case_idx, a.img_idx, CENTER_PIC_ID, root=a.data_root)
+            if not a.stitch:
+                center_img = None
     elif a.synth:
         from .synth import CONFIGS, synth_pair
         w, h, n, m, seed = CONFIGS[a.synth]
@@ -223,7 +239,7 @@ def main(argv=None):
         src, dst, Hg, other_shape, center_shape, other_img = p.src, p.dst, p.Hg, p.shape, p.shape, p.img
         center_img = (np.random.default_rng(seed + 1).integers(0, 256, p.shape, dtype=np.uint8) if a.stitch else None)
     else:
-        ap.error("the reference's dataset (../diff_1) is not distributed: give --pair or --synth")
+        ap.error("the reference's dataset (../diff_1) is not distributed: give --data-root, --pair or --synth")
 
     flat, warped = run_pair(src, dst, Hg, other_shape, center_shape, par["mesh_size"], par["gamma"], par["sigma"],
                             other_img=other_img, center_img=center_img, device=a.device)

@@ -323,4 +323,57 @@ int apap_equalize_hist(const uint8_t *img, int h, int w, int channels, uint8_t *
     return APAP_OK;
 }
 
+int apap_find_homography_ransac(const float *src, const float *dst, int n, double thresh, int iterations,
+                                unsigned long long seed, double *H_out, uint8_t *mask_out, int *inliers_out,
+                                int device) {
+    if (!src || !dst || !H_out || !mask_out || !inliers_out)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_find_homography_ransac: null argument");
+    if (n < 4) return apap::fail(APAP_ERR_INVALID_ARG, "apap_find_homography_ransac: n=%d, a homography needs 4 points", n);
+    int result[2] = {0, 0};
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int dev;
+        int rc = select_device(device, &dev);
+        if (rc) return rc;
+        const size_t pt_bytes = (size_t)n * 2 * sizeof(float);
+        const size_t work_bytes = apap_ransac_workspace_bytes(n, iterations);
+        void *d_src, *d_dst, *d_work, *d_H, *d_mask, *d_result;
+        if ((rc = slot_get(S_IMG, pt_bytes, dev, &d_src))) return rc;
+        if ((rc = slot_get(S_AUX, pt_bytes, dev, &d_dst))) return rc;
+        if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
+        if ((rc = slot_get(S_DENORM, 9 * sizeof(double), dev, &d_H))) return rc;
+        if ((rc = slot_get(S_OUT, (size_t)n, dev, &d_mask))) return rc;
+        if ((rc = slot_get(S_STATUS, 2 * sizeof(int), dev, &d_result))) return rc;
+        APAP_HIP_TRY(hipMemcpyAsync(d_src, src, pt_bytes, hipMemcpyHostToDevice, nullptr));
+        APAP_HIP_TRY(hipMemcpyAsync(d_dst, dst, pt_bytes, hipMemcpyHostToDevice, nullptr));
+        rc = apap_ransac_device((const float *)d_src, (const float *)d_dst, n, thresh, iterations, seed, (double *)d_H,
+                                (uint8_t *)d_mask, (int *)d_result, d_work, work_bytes, nullptr);
+        if (rc) return rc;
+        APAP_HIP_TRY(hipMemcpyAsync(mask_out, d_mask, (size_t)n, hipMemcpyDeviceToHost, nullptr));
+        APAP_HIP_TRY(hipMemcpyAsync(result, d_result, sizeof(result), hipMemcpyDeviceToHost, nullptr));
+        APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    *inliers_out = result[1];
+    if (result[1] < 4) {  // cv.findHomography returns no model
+        memset(mask_out, 0, (size_t)n);
+        return APAP_OK;
+    }
+    // re-fit to the inliers with the hot path's own normalised DLT: one cell, every weight 1
+    std::vector<float> s_in, d_in;
+    s_in.reserve((size_t)2 * result[1]);
+    d_in.reserve((size_t)2 * result[1]);
+    for (int k = 0; k < n; ++k) {
+        if (!mask_out[k]) continue;
+        s_in.push_back(src[2 * k]); s_in.push_back(src[2 * k + 1]);
+        d_in.push_back(dst[2 * k]); d_in.push_back(dst[2 * k + 1]);
+    }
+    const double vertex[2] = {0.0, 0.0};
+    float H32[9];
+    const int rc = apap_local_homography(s_in.data(), d_in.data(), (int)(s_in.size() / 2), vertex, 1, 1, 1.0, 1.0, H32,
+                                         nullptr, device);
+    if (rc) return rc;
+    for (int i = 0; i < 9; ++i) H_out[i] = (double)H32[i];
+    return APAP_OK;
+}
+
 }  // extern "C"

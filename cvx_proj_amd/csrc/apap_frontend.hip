@@ -304,9 +304,207 @@ int launch_equalize(const uint8_t *d_img, size_t bytes, int total, uint8_t *d_ou
     return APAP_OK;
 }
 
+// --------------------------------------------------------------------------------
+// Seed homography by RANSAC (contract of cv.findHomography(src, dst, cv.RANSAC, thresh),
+// baseline_stitch_test.py:42; specification: oracle/frontend_oracle.py, bit for bit).
+// R1 k_ransac_hyp: one lane per hypothesis - counter-based sampler (splitmix64), 8 x 8 Gaussian
+//    elimination with partial pivoting on a lane-private 8 x 9 system kept in LDS (dynamic row
+//    indices; index-major layout, so the 64 lanes never conflict).  Products and differences are
+//    rounded separately (the library is built with -ffp-contract=off), as in the oracle.
+// R2 k_ransac_score: one block per hypothesis counts the points within the threshold.
+// R3 k_ransac_select: first hypothesis with the most inliers, its matrix and its mask.
+// A few thousand tiny solves and a few million point tests: launch-latency-bound, no roofline.
+// --------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    unsigned long long z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+constexpr int kHypLanes = 64;
+
+__global__ __launch_bounds__(kHypLanes) void k_ransac_hyp(const float *__restrict__ src, const float *__restrict__ dst,
+                                                          int n, int iterations, unsigned long long seed,
+                                                          double *__restrict__ H /* iterations x 9 */) {
+    __shared__ double sys[72][kHypLanes];
+    const int t = threadIdx.x;
+    const int h = blockIdx.x * kHypLanes + t;
+    if (h >= iterations) return;  // lane-private work below: no barriers
+#define A(r, c) sys[(r) * 9 + (c)][t]
+    // four distinct indices: draw j is taken modulo n - j, then stepped over the earlier picks
+    // in ascending order
+    int pick[4];
+    for (int j = 0; j < 4; ++j) {
+        const unsigned int r = (unsigned int)(splitmix64(seed + 4ull * (unsigned long long)h + (unsigned long long)j) >> 32);
+        int p = (int)(r % (unsigned int)(n - j));
+        int prev[3];
+        for (int k = 0; k < j; ++k) prev[k] = pick[k];
+        for (int a = 1; a < j; ++a) {  // insertion sort of at most three earlier picks
+            const int v = prev[a];
+            int b = a - 1;
+            while (b >= 0 && prev[b] > v) { prev[b + 1] = prev[b]; --b; }
+            prev[b + 1] = v;
+        }
+        for (int k = 0; k < j; ++k) p += (p >= prev[k]) ? 1 : 0;
+        pick[j] = p;
+    }
+    for (int j = 0; j < 4; ++j) {
+        const double x = (double)src[2 * pick[j]], y = (double)src[2 * pick[j] + 1];
+        const double u = (double)dst[2 * pick[j]], v = (double)dst[2 * pick[j] + 1];
+        const int r0 = 2 * j, r1 = 2 * j + 1;
+        A(r0, 0) = x; A(r0, 1) = y; A(r0, 2) = 1.0; A(r0, 3) = 0.0; A(r0, 4) = 0.0; A(r0, 5) = 0.0;
+        A(r0, 6) = -(u * x); A(r0, 7) = -(u * y); A(r0, 8) = u;
+        A(r1, 0) = 0.0; A(r1, 1) = 0.0; A(r1, 2) = 0.0; A(r1, 3) = x; A(r1, 4) = y; A(r1, 5) = 1.0;
+        A(r1, 6) = -(v * x); A(r1, 7) = -(v * y); A(r1, 8) = v;
+    }
+    bool ok = true;
+    for (int c = 0; c < 8; ++c) {
+        int p = c;
+        double best = fabs(A(c, c));
+        for (int r = c + 1; r < 8; ++r) {
+            const double v = fabs(A(r, c));
+            if (v > best) { best = v; p = r; }  // first largest
+        }
+        if (p != c) {
+            for (int cc = 0; cc < 9; ++cc) {
+                const double tmp = A(p, cc);
+                A(p, cc) = A(c, cc);
+                A(c, cc) = tmp;
+            }
+        }
+        const double piv = A(c, c);
+        ok = ok && piv != 0.0 && isfinite(piv);
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = A(r, c) / piv;
+            for (int cc = c; cc < 9; ++cc) {
+                const double prod = f * A(c, cc);
+                A(r, cc) = A(r, cc) - prod;
+            }
+        }
+    }
+    double sol[8];
+    for (int i = 7; i >= 0; --i) {
+        double s = A(i, 8);
+        for (int j = i + 1; j < 8; ++j) {
+            const double prod = A(i, j) * sol[j];
+            s = s - prod;
+        }
+        sol[i] = s / A(i, i);
+    }
+#undef A
+    const double nan = __builtin_nan("");
+    for (int i = 0; i < 8; ++i) H[(size_t)h * 9 + i] = ok ? sol[i] : nan;
+    H[(size_t)h * 9 + 8] = ok ? 1.0 : nan;
+}
+
+// squared forward reprojection error, operations in the oracle's order
+__device__ __forceinline__ bool ransac_inlier(const double (&h)[9], double x, double y, double u, double v, double thr2) {
+    const double w = (h[6] * x + h[7] * y) + h[8];
+    const double px = ((h[0] * x + h[1] * y) + h[2]) / w;
+    const double py = ((h[3] * x + h[4] * y) + h[5]) / w;
+    const double dx = px - u, dy = py - v;
+    return dx * dx + dy * dy <= thr2;  // NaN compares false
+}
+
+__global__ __launch_bounds__(256) void k_ransac_score(const float *__restrict__ src, const float *__restrict__ dst, int n,
+                                                      const double *__restrict__ H, double thr2,
+                                                      int *__restrict__ counts) {
+    __shared__ int s_part[4];
+    double h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = H[(size_t)blockIdx.x * 9 + i];
+    int c = 0;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float2 s = reinterpret_cast<const float2 *>(src)[k];
+        const float2 d = reinterpret_cast<const float2 *>(dst)[k];
+        c += ransac_inlier(h, (double)s.x, (double)s.y, (double)d.x, (double)d.y, thr2) ? 1 : 0;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(256) void k_ransac_select(const float *__restrict__ src, const float *__restrict__ dst, int n,
+                                                       const double *__restrict__ H, const int *__restrict__ counts,
+                                                       int iterations, double thr2, double *__restrict__ H_best,
+                                                       uint8_t *__restrict__ mask, int *__restrict__ result) {
+    __shared__ int s_cnt[256], s_idx[256];
+    int bc = -1, bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < iterations; i += 256) {  // ascending: strictly greater keeps the first
+        const int c = counts[i];
+        if (c > bc) { bc = c; bi = i; }
+    }
+    s_cnt[threadIdx.x] = bc;
+    s_idx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            const int oc = s_cnt[threadIdx.x + d], oi = s_idx[threadIdx.x + d];
+            if (oc > s_cnt[threadIdx.x] || (oc == s_cnt[threadIdx.x] && oi < s_idx[threadIdx.x])) {
+                s_cnt[threadIdx.x] = oc;
+                s_idx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int best = s_idx[0];
+    double h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = H[(size_t)best * 9 + i];
+    if (threadIdx.x < 9) H_best[threadIdx.x] = h[threadIdx.x];
+    if (threadIdx.x == 0) {
+        result[0] = best;
+        result[1] = s_cnt[0];
+    }
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const float2 s = reinterpret_cast<const float2 *>(src)[k];
+        const float2 d = reinterpret_cast<const float2 *>(dst)[k];
+        mask[k] = ransac_inlier(h, (double)s.x, (double)s.y, (double)d.x, (double)d.y, thr2) ? 1 : 0;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t apap_ransac_workspace_bytes(int n, int iterations) {
+    if (n < 4 || iterations < 1) return 0;
+    return (size_t)iterations * 9 * sizeof(double) + (size_t)iterations * sizeof(int);
+}
+
+int apap_ransac_device(const float *d_src, const float *d_dst, int n, double thresh, int iterations,
+                       unsigned long long seed, double *d_H_best, uint8_t *d_mask, int *d_result, void *d_work,
+                       size_t work_bytes, void *stream) {
+    if (!d_src || !d_dst || !d_H_best || !d_mask || !d_result || !d_work)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_ransac_device: null device pointer");
+    if (n < 4 || iterations < 1 || iterations > (1 << 24) || !(thresh >= 0.0))
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_ransac_device: n=%d (need >= 4) iterations=%d thresh=%g", n,
+                          iterations, thresh);
+    if (work_bytes < apap_ransac_workspace_bytes(n, iterations))
+        return apap::fail(APAP_ERR_WORKSPACE, "apap_ransac_device: workspace %zu < %zu bytes", work_bytes,
+                          apap_ransac_workspace_bytes(n, iterations));
+    if (((uintptr_t)d_work & 7) != 0 || ((uintptr_t)d_src & 7) != 0 || ((uintptr_t)d_dst & 7) != 0)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_ransac_device: points and workspace must be 8-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    double *H = (double *)d_work;
+    int *counts = (int *)(H + (size_t)iterations * 9);
+    const double thr2 = thresh * thresh;
+    {
+        apap::ProfScope prof(APAP_PROF_RANSAC, s);
+        hipLaunchKernelGGL(k_ransac_hyp, dim3((iterations + kHypLanes - 1) / kHypLanes), dim3(kHypLanes), 0, s, d_src,
+                           d_dst, n, iterations, seed, H);
+        hipLaunchKernelGGL(k_ransac_score, dim3(iterations), dim3(256), 0, s, d_src, d_dst, n, (const double *)H, thr2,
+                           counts);
+        hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, s, d_src, d_dst, n, (const double *)H,
+                           (const int *)counts, iterations, thr2, d_H_best, d_mask, d_result);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "apap_ransac_device launch");
+    return APAP_OK;
+}
 
 size_t apap_equalize_workspace_bytes(int channels) {
     if (channels < 1 || channels > kEqMaxChannels) return 0;

@@ -247,6 +247,27 @@ size_t apap_equalize_workspace_bytes(int channels);
 int apap_equalize_hist_device(const uint8_t *d_img, int h, int w, int channels, uint8_t *d_out, void *d_work,
                               size_t work_bytes, void *stream);
 
+/* Seed homography, the contract of baseline_stitch_test.py:42
+ *     H, mask = cv.findHomography(src_pts, dst_pts, cv.RANSAC, thresh)
+ * src, dst: n x 2 float32.  `iterations` 4-point hypotheses drawn by a counter-based sampler
+ * (`seed`), forward reprojection error against thresh, the first hypothesis with the most
+ * inliers wins; H_out (9 doubles, row-major, H[8] = 1) is the normalised DLT of the hot path
+ * (apap.py:35-119,160-168, all weights 1) re-fitted to its inliers; mask_out: n bytes 0/1.
+ * *inliers_out < 4 means no model (cv returns None): H_out is then left untouched.  This is this
+ * repository's estimator, not OpenCV's (sampler, adaptive stopping and LM polish differ):
+ * oracle/frontend_oracle.py is its specification. */
+#define APAP_RANSAC_ITERATIONS 2048
+#define APAP_RANSAC_SEED 0x5EEDC0DE5EEDC0DEull
+int apap_find_homography_ransac(const float *src, const float *dst, int n, double thresh, int iterations,
+                                unsigned long long seed, double *H_out, uint8_t *mask_out, int *inliers_out,
+                                int device);
+size_t apap_ransac_workspace_bytes(int n, int iterations);
+/* Device half (no re-fit): d_H_best 9 doubles = the winning 4-point model, d_mask n bytes,
+ * d_result 2 ints = {winning hypothesis, its inlier count}.  Points 8-byte aligned. */
+int apap_ransac_device(const float *d_src, const float *d_dst, int n, double thresh, int iterations,
+                       unsigned long long seed, double *d_H_best, uint8_t *d_mask, int *d_result, void *d_work,
+                       size_t work_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

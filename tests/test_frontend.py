@@ -188,3 +188,157 @@ def test_equalize_device_entry_any_alignment(native):
     rc = native.lib().apap_equalize_hist_device(buf_in.data_ptr(), h, w, c, buf_out.data_ptr(), work.data_ptr(),
                                                 8, ctypes.c_void_p(0))
     assert rc == native.ERR_WORKSPACE
+
+
+# ------------------------------------------------------------------ RANSAC seed homography
+def ransac_case(n=600, outliers=0.3, noise=0.7, seed=0, size=(1920, 1080)):
+    rng = np.random.default_rng(seed)
+    Hg = np.array([[1.02, 0.01, 30.0], [-0.015, 0.99, -20.0], [1e-5, -2e-5, 1.0]])
+    src = (rng.random((n, 2)) * size).astype(np.float32)
+    q = np.c_[src.astype(np.float64), np.ones(n)] @ Hg.T
+    dst = (q[:, :2] / q[:, 2:] + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    out = rng.random(n) < outliers
+    dst[out] = (rng.random((int(out.sum()), 2)) * size).astype(np.float32)
+    return src, dst, Hg, out
+
+
+def degenerate_case(n=40):
+    """Source points on one line (exactly, in float32): no 4 of them determine a homography."""
+    t = np.arange(n, dtype=np.float32)
+    line = np.stack([t, 2 * t], axis=1)
+    other = (np.random.default_rng(5).random((n, 2)) * 1000).astype(np.float32)
+    return line, other
+
+
+def test_oracle_ransac_sampler_is_distinct_uniform_and_reproducible():
+    for n in (4, 5, 9, 1000):
+        p = F.ransac_sample(n, 4096)
+        assert p.min() >= 0 and p.max() < n
+        s = np.sort(p, axis=1)
+        assert (s[:, 1:] != s[:, :-1]).all()
+        assert np.array_equal(p, F.ransac_sample(n, 4096))
+    counts = np.bincount(F.ransac_sample(16, 1 << 14).ravel(), minlength=16)
+    assert counts.min() > 0.9 * counts.mean() and counts.max() < 1.1 * counts.mean()
+    assert not np.array_equal(F.ransac_sample(50, 64, seed=1), F.ransac_sample(50, 64, seed=2))
+
+
+def test_oracle_ransac_minimal_solver():
+    rng = np.random.default_rng(1)
+    Hg = np.array([[0.9, 0.05, 12.0], [-0.03, 1.1, -7.0], [2e-4, -1e-4, 1.0]])
+    src4 = rng.random((64, 4, 2)) * 500
+    q = np.concatenate([src4, np.ones((64, 4, 1))], axis=-1) @ Hg.T
+    dst4 = q[..., :2] / q[..., 2:]
+    H = F.ransac_minimal_solve(src4, dst4)
+    assert np.allclose(H, Hg.ravel(), rtol=1e-6, atol=1e-7)
+    # collinear source points: singular system -> NaN row, never an inlier
+    src4[0] = [[0, 0], [1, 1], [2, 2], [3, 3]]
+    H = F.ransac_minimal_solve(src4, dst4)
+    assert np.isnan(H[0]).all() and np.isfinite(H[1:]).all()
+    assert not (F.ransac_errors(H[:1], src4[1].astype(np.float32), dst4[1].astype(np.float32)) <= 25).any()
+
+
+def test_oracle_ransac_recovers_inliers_and_model():
+    src, dst, Hg, out = ransac_case()
+    H, mask = F.ransac_homography(src, dst)
+    assert mask.shape == (len(src), 1) and mask.dtype == np.uint8
+    assert not (mask.ravel().astype(bool) & out).any()           # no gross outlier accepted
+    assert mask.sum() >= 0.98 * (~out).sum()
+    q = np.c_[src.astype(np.float64), np.ones(len(src))]
+    a, b = q @ H.T, q @ Hg.T
+    assert np.abs(a[:, :2] / a[:, 2:] - b[:, :2] / b[:, 2:]).max() < 0.5
+    assert H[2, 2] == 1.0
+    # collinear source points: every 4-point system is singular -> no model (cv returns None)
+    line, other = degenerate_case()
+    H, mask = F.ransac_homography(line, other, iterations=64)
+    assert H is None and mask.sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,outliers,seed", [(600, 0.3, 0), (2000, 0.5, 1), (8, 0.0, 2), (4, 0.0, 3), (57, 0.2, 4)])
+def test_ransac_device_half_is_bit_identical_to_the_oracle(native, n, outliers, seed):
+    """Sampler, minimal solver, inlier counts, winner and mask: equal bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    src, dst, _, _ = ransac_case(n, outliers, seed=seed)
+    K = 512
+    core = F.ransac_core(src, dst, 5.0, K, F.RANSAC_SEED)
+    d_src, d_dst = torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)
+    wb = native.lib().apap_ransac_workspace_bytes(n, K)
+    work = torch.zeros(wb, dtype=torch.uint8, device=dev)
+    Hb = torch.zeros(9, dtype=torch.float64, device=dev)
+    mask = torch.zeros(n, dtype=torch.uint8, device=dev)
+    res = torch.zeros(2, dtype=torch.int32, device=dev)
+    native.check(native.lib().apap_ransac_device(d_src.data_ptr(), d_dst.data_ptr(), n, 5.0, K, ctypes.c_ulonglong(F.RANSAC_SEED),
+                                                 Hb.data_ptr(), mask.data_ptr(), res.data_ptr(), work.data_ptr(), wb,
+                                                 ctypes.c_void_p(0)))
+    torch.cuda.synchronize()
+    H_all = work.cpu().numpy()[:K * 72].view(np.float64).reshape(K, 9)
+    counts = work.cpu().numpy()[K * 72:K * 76].view(np.int32)
+    assert np.array_equal(np.isnan(H_all), np.isnan(core["H"]))
+    same = np.nan_to_num(H_all) == np.nan_to_num(core["H"])
+    assert same.all(), f"{int((~same).sum())} of {same.size} hypothesis entries differ"
+    assert np.array_equal(counts, core["counts"])
+    assert res.cpu().tolist() == [core["best"], core["count"]]
+    assert np.array_equal(mask.cpu().numpy(), core["mask"])
+    assert np.array_equal(Hb.cpu().numpy(), core["H"][core["best"]])
+
+
+@pytest.mark.gpu
+def test_find_homography_vs_oracle_and_contract(native):
+    src, dst, Hg, out = ransac_case(900, 0.35, seed=7)
+    H, mask = native.find_homography_ransac(src, dst, 5.0)
+    H_ref, mask_ref = F.ransac_homography(src, dst, 5.0)
+    assert H.shape == (3, 3) and H.dtype == np.float64 and mask.shape == (900, 1) and mask.dtype == np.uint8
+    assert np.array_equal(mask, mask_ref)
+    assert np.array_equal(H, H_ref), np.abs(H - H_ref).max()      # the re-fit is the hot path: bit-exact float32
+    assert not (mask.ravel().astype(bool) & out).any() and mask.sum() >= 0.98 * (~out).sum()
+    # no model
+    line, other = degenerate_case()
+    H, mask = native.find_homography_ransac(line, other, iterations=64)
+    assert H is None and mask.sum() == 0
+    with pytest.raises(native.ApapError):
+        native.find_homography_ransac(src[:3], dst[:3])
+
+
+@pytest.mark.gpu
+def test_cli_reference_flow_on_a_dataset_directory(native, tmp_path):
+    """apap.py __main__ end to end (apap.py:236-265) on a synthetic dataset in the reference's
+    layout: PNG read, equalisation, keypoints.mat, RANSAC seed, hot path, .mat output."""
+    import scipy.io
+    from PIL import Image
+    from cvx_proj_amd import apap as A
+    from oracle import apap_oracle as O
+    root = tmp_path / "raw_data"
+    base = root / "case1"
+    (base / "scat").mkdir(parents=True)
+    (base / "no_scat").mkdir()
+    rng = np.random.default_rng(0)
+    h, w = 240, 320
+    for i in range(1, 6):
+        for sub, stem in (("scat", "img_haze"), ("no_scat", "img_nohaze")):
+            Image.fromarray(natural_like(h, w, 3, i)).save(base / sub / f"{stem}{i}.png")
+    src, dst, Hg, out = ransac_case(300, 0.25, noise=0.4, seed=9, size=(w, h))
+    cells = np.empty((4, 1), dtype=object)
+    for k in range(4):
+        m = np.ones((6, len(src)))
+        m[0:2], m[3:5] = src.T, dst.T           # centre picture's points, other picture's points
+        cells[k, 0] = m
+    scipy.io.savemat(base / "keypoints.mat", {"keypoints": cells})
+    out_prefix = str(tmp_path / "results") + "/"
+    warp_file = str(tmp_path / "stitch.npy")
+    assert A.main(["1", "2", "--data-root", str(root), "--mesh-size", "12", "--out-prefix", out_prefix,
+                   "--stitch", warp_file]) == 0
+    flat = scipy.io.loadmat(out_prefix + "case1/H32_apap.mat")["H"]
+    assert flat.shape == (144, 9) and flat.dtype == np.float64
+    # the same flow through the oracles
+    H_ref, mask_ref = F.ransac_homography(src, dst, 5.0)
+    keep = mask_ref.ravel() > 0
+    Hswap = np.linalg.inv(H_ref)
+    fsrc, fdst = dst[keep], src[keep]           # swap=True: other picture's points first
+    pic = np.empty((h, w, 3), dtype=np.uint8)    # final_size only reads .shape (apap.py:240)
+    fw, fh, ox, oy = O.final_size(pic, pic, Hswap)
+    vertices = O.get_vertice((fw, fh), 12, (ox, oy))
+    Hl, _ = O.local_homography_loop(fsrc, fdst, vertices, 0.5, 100, want_weights=False)
+    assert np.array_equal(flat, O.invert_normalize_flatten(Hl))
+    canvas = np.load(warp_file)
+    assert canvas.shape == (fh, fw, 3) and canvas.any()
