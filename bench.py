@@ -110,6 +110,24 @@ class Resident:
         N.check(N.lib().apap_equalize_hist_device(self.img.data_ptr(), p.shape[0], p.shape[1], 3, self.eq_out.data_ptr(),
                                                   self.eq_work.data_ptr(), self.eq_work.numel(), ctypes.c_void_p(stream)))
 
+    def ransac(self, stream):
+        """Device half of the seed-homography estimator (baseline_stitch_test.py:42) on the pair's
+        correspondences; timed as an extra, not part of ``value``."""
+        p = self.pair
+        if not hasattr(self, "r_src"):
+            dev = self.img.device
+            self.r_src = torch.from_numpy(np.ascontiguousarray(p.src, dtype=np.float32)).to(dev)
+            self.r_dst = torch.from_numpy(np.ascontiguousarray(p.dst, dtype=np.float32)).to(dev)
+            self.r_wb = N.lib().apap_ransac_workspace_bytes(self.n, N.RANSAC_ITERATIONS)
+            self.r_work = torch.zeros(self.r_wb, dtype=torch.uint8, device=dev)
+            self.r_H = torch.zeros(9, dtype=torch.float64, device=dev)
+            self.r_mask = torch.zeros(self.n, dtype=torch.uint8, device=dev)
+            self.r_res = torch.zeros(2, dtype=torch.int32, device=dev)
+        N.check(N.lib().apap_ransac_device(self.r_src.data_ptr(), self.r_dst.data_ptr(), self.n, 5.0, N.RANSAC_ITERATIONS,
+                                           ctypes.c_ulonglong(N.RANSAC_SEED), self.r_H.data_ptr(), self.r_mask.data_ptr(),
+                                           self.r_res.data_ptr(), self.r_work.data_ptr(), self.r_wb,
+                                           ctypes.c_void_p(stream)))
+
     def stitch(self, stream):
         """Fused warp + paste + uniform_blend (the reference's commented-out tail,
         apap.py:258-262); timed as an extra, not part of ``value``."""
@@ -283,6 +301,16 @@ def main():
         torch.cuda.synchronize()
         t_eq = time.perf_counter() - t0
 
+    t_ransac = None
+    if hasattr(res, "ransac"):
+        res.ransac(stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            res.ransac(stream)
+        torch.cuda.synchronize()
+        t_ransac = time.perf_counter() - t0
+
     # per-kernel durations, HIP events on the launch stream (rank-local)
     N.lib().apap_profile_enable(1)
     for _ in range(a.steps):
@@ -290,6 +318,8 @@ def main():
         res.warp(stream)
         if t_eq is not None:
             res.equalize(stream)
+        if t_ransac is not None:
+            res.ransac(stream)
     torch.cuda.synchronize()
     ms = (ctypes.c_float * N.PROF_SLOTS)()
     cnt = (ctypes.c_int * N.PROF_SLOTS)()
@@ -343,6 +373,11 @@ def main():
                              "frac": 3.0 * pair.img.size / ((kern["eq_hist"] + kern["eq_apply"]) * 1e-3) / 1e9 / PEAK_HBM_GBS},
                 "note": "per-channel cv.equalizeHist of the 4K source image, utils.py:85-91; algorithmic "
                         "traffic 3 bytes per image byte (read, read, write); extra, not in `value`"},
+            "ransac": None if t_ransac is None else {
+                "ms_per_call": t_ransac / a.steps * 1e3, "hypotheses": N.RANSAC_ITERATIONS, "points": res.n,
+                "inliers": int(res.r_res.cpu()[1]),
+                "note": "device half of the seed homography (4-point hypotheses, 5 px), baseline_stitch_test.py:42; "
+                        "three small kernels, launch-latency-bound; extra, not in `value`"},
             "kernels_ms": kern,
             "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
