@@ -280,32 +280,34 @@ __device__ __forceinline__ double cell_weight_sq_tab(double vx, double vy, doubl
 }
 
 // --------------------------------------------------------------------------------
-// K1 (VALU variant): lanes = cells.  A block is 4 waves on the SAME 64 cells; wave s
-// walks its quarter of the block's keypoint split (split = blockIdx.y).
+// K1 (VALU variant): lanes = cells, one wave per 64-cell tile and keypoint split (grid.y).
 // Per keypoint the 32 table doubles are wave-uniform: they arrive through the scalar
 // cache into SGPRs and feed v_fma_f64 as the scalar operand, so the vector unit only
-// executes the weight and 30 FMAs.  The four partial sums are added in LDS in a fixed
-// order (bitwise reproducible), grid-level splits go to separate slabs that K2 adds.
+// executes the weight and 30 FMAs.  Grid-level splits go to separate slabs that K2 adds.
 // --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
                                                        int cells_pad, double gamma2, double inv_sigma2,
                                                        int pts_per_split, double *__restrict__ moments,
                                                        BatchStride bs) {
-    __shared__ double red[3][kMoments][kWave];
+    __shared__ double s_exp2[kExpN];
+    for (int j = threadIdx.x; j < kExpN; j += 256) s_exp2[j] = kExp2Tab[j];
+    __syncthreads();
     table += (long long)blockIdx.z * bs.table;
     vertices += (long long)blockIdx.z * bs.vertices;
     moments += (long long)blockIdx.z * bs.moments;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cell = blockIdx.x * kWave + lane;
+    // the block's four waves own four different 64-cell tiles and walk the SAME keypoints, so a
+    // table row fetched through the scalar cache by one wave is a hit for the other three
+    const int cell = (blockIdx.x * 4 + wave) * kWave + lane;
+    if (cell - lane >= cells_pad) return;  // wave-uniform; no barrier below
     const int cc = min(cell, cells - 1);
     const double vx = vertices[2 * cc];
     const double vy = vertices[2 * cc + 1];
-    const int pts_per_wave = pts_per_split / 4;  // pts_per_split is a multiple of 4
-    const int split_end = min(n, (int)(blockIdx.y + 1) * pts_per_split);
-    const int p0 = min(split_end, (int)blockIdx.y * pts_per_split + wave * pts_per_wave);
-    const int p1 = min(split_end, p0 + pts_per_wave);
+    const int p0 = min(n, (int)blockIdx.y * pts_per_split);
+    const int p1 = min(n, p0 + pts_per_split);
+    const double scaled_inv_sigma2 = inv_sigma2 * kExpScale;
 
     double acc[kMoments];
 #pragma unroll
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict_
 
     // The keypoint's (x, y) is fetched one iteration ahead: scalar loads return out of
     // order, so the only usable wait is lgkmcnt(0); with x, y already in SGPRs the weight
-    // (~40 VALU instructions) runs while this iteration's 30 products are in flight.
+    // (~25 VALU instructions) runs while this iteration's 30 products are in flight.
     double sx = 0.0, sy = 0.0;
     if (p0 < p1) {
         sx = table[(size_t)p0 * APAP_TABLE_STRIDE + 30];
@@ -326,30 +328,20 @@ __global__ __launch_bounds__(256) void k_assemble_valu(const double *__restrict_
         const double *__restrict__ row = table + (size_t)p * APAP_TABLE_STRIDE;
         const double *__restrict__ nxt = table + (size_t)min(p + 1, p1 - 1) * APAP_TABLE_STRIDE;
         const double nsx = nxt[30], nsy = nxt[31];
-        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above the weight computation
-        const double w2 = cell_weight_sq(vx, vy, sx, sy, inv_sigma2, gamma2);
+        double r[kMoments];
 #pragma unroll
-        for (int j = 0; j < kMoments; ++j) acc[j] = fma(w2, row[j], acc[j]);
+        for (int j = 0; j < kMoments; ++j) r[j] = row[j];
+        __builtin_amdgcn_sched_barrier(0);  // all scalar loads of the iteration are issued above the weight
+        const double w2 = cell_weight_sq_tab(vx, vy, sx, sy, scaled_inv_sigma2, gamma2, s_exp2);
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) acc[j] = fma(w2, r[j], acc[j]);
+        __builtin_amdgcn_sched_barrier(0);  // or the copy is hoisted to the loop top with its own lgkmcnt(0)
         sx = nsx;
         sy = nsy;
     }
-
-    if (wave > 0) {
+    double *dst = moments + (size_t)blockIdx.y * kMoments * cells_pad + cell;
 #pragma unroll
-        for (int j = 0; j < kMoments; ++j) red[wave - 1][j][lane] = acc[j];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        double *dst = moments + (size_t)blockIdx.y * kMoments * cells_pad + cell;
-#pragma unroll
-        for (int j = 0; j < kMoments; ++j) {
-            double s = acc[j];
-            s += red[0][j][lane];
-            s += red[1][j][lane];
-            s += red[2][j][lane];
-            dst[(size_t)j * cells_pad] = s;
-        }
-    }
+    for (int j = 0; j < kMoments; ++j) dst[(size_t)j * cells_pad] = acc[j];
 }
 
 // --------------------------------------------------------------------------------
@@ -1348,7 +1340,10 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch) {
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 4096;
     }();
-    while (splits < 32 && (long long)p.cell_tiles * batch * 4 * splits < want_waves && n / (splits * 2) >= kChunk) splits *= 2;
+    // waves per (64-cell tile, split): the MFMA kernel's block is 4 waves on one tile, the VALU
+    // kernel's is 4 waves on 4 tiles
+    const int waves_per_tile = variant == APAP_VARIANT_MFMA ? 4 : 1;
+    while (splits < 32 && (long long)p.cell_tiles * batch * waves_per_tile * splits < want_waves && n / (splits * 2) >= kChunk) splits *= 2;
     int pps = (n + splits - 1) / splits;
     pps = (pps + kChunk - 1) / kChunk * kChunk;
     p.splits = (n + pps - 1) / pps;  // no empty split
@@ -1410,8 +1405,8 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
             hipLaunchKernelGGL(k_assemble_mfma<4>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
                                inv_sigma2, p.pts_per_split, moments, bs);
         else
-            hipLaunchKernelGGL(k_assemble_valu, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
-                               inv_sigma2, p.pts_per_split, moments, bs);
+            hipLaunchKernelGGL(k_assemble_valu, dim3((p.cell_tiles + 3) / 4, p.splits, batch), dim3(256), 0, s, d_tables, n,
+                               d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
     }
     const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
     {
