@@ -77,3 +77,57 @@ def test_fuzz_solve_and_warp(native, seed):
     if oy + c["img"].shape[0] <= fh and ox + c["img"].shape[1] <= fw and not diff.any():
         st, _ = native.local_stitch(c["img"], center, good, c["mesh"][0], c["mesh"][1], fw, fh, ox, oy)
         assert np.array_equal(st, O.stitch(ref, center, (ox, oy)))
+
+
+# ------------------------------------------------------------------ callers of the path
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_equalize(native, seed):
+    """Random shapes (1..4 channels, sizes around the 3 KiB chunk and 16-byte boundaries) and
+    value distributions (uniform, narrow band, two levels, heavy single bin)."""
+    from oracle import frontend_oracle as F
+    rng = np.random.default_rng(1000 + seed)
+    c = int(rng.integers(1, 5))
+    h, w = int(rng.integers(1, 90)), int(rng.integers(1, 130))
+    if seed % 6 == 0:      # exactly whole chunks / one byte more / one byte less
+        total = 3072 * int(rng.integers(1, 4)) + int(rng.integers(-1, 2))
+        h, w, c = 1, max(total // 3, 1), 3
+    kind = seed % 4
+    if kind == 0:
+        img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+    elif kind == 1:
+        lo = int(rng.integers(0, 200))
+        img = rng.integers(lo, lo + int(rng.integers(1, 30)), (h, w, c), dtype=np.uint8)
+    elif kind == 2:
+        img = rng.choice(np.array([7, 201], dtype=np.uint8), size=(h, w, c), p=[0.9, 0.1])
+    else:
+        img = np.where(rng.random((h, w, c)) < 0.97, 128, rng.integers(0, 256, (h, w, c))).astype(np.uint8)
+    out = native.equalize_hist(img)
+    assert np.array_equal(out, F.equalize_hist_image(img)), (h, w, c, kind)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_ransac(native, seed):
+    """Random point counts, outlier ratios, noise and thresholds: mask and re-fitted model equal
+    the oracle's (sampler, solver and scoring are integer / IEEE-exact on both sides)."""
+    from oracle import frontend_oracle as F
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.choice([4, 5, 7, 16, 100, 333, 1500]))
+    w, h = rng.integers(50, 4000, 2)
+    Hg = np.array([[rng.uniform(0.8, 1.2), rng.normal(0, 0.05), rng.normal(0, 0.1 * w)],
+                   [rng.normal(0, 0.05), rng.uniform(0.8, 1.2), rng.normal(0, 0.1 * h)],
+                   [rng.normal(0, 1e-4), rng.normal(0, 1e-4), 1.0]])
+    src = (rng.random((n, 2)) * [w, h]).astype(np.float32)
+    q = np.c_[src.astype(np.float64), np.ones(n)] @ Hg.T
+    dst = (q[:, :2] / q[:, 2:] + rng.normal(0, rng.uniform(0, 2), (n, 2))).astype(np.float32)
+    bad = rng.random(n) < rng.uniform(0, 0.6)
+    dst[bad] = (rng.random((int(bad.sum()), 2)) * [w, h]).astype(np.float32)
+    thresh = float(rng.choice([0.5, 3.0, 5.0, 20.0]))
+    iters = int(rng.choice([1, 33, 256, 2048]))
+    H, mask = native.find_homography_ransac(src, dst, thresh, iterations=iters, seed=seed)
+    H_ref, mask_ref = F.ransac_homography(src, dst, thresh, iterations=iters, seed=seed)
+    assert np.array_equal(mask, mask_ref)
+    assert (H is None) == (H_ref is None)
+    if H is not None:
+        # the re-fit is the hot path on the inliers: float32-exact except for nearly
+        # degenerate inlier sets (same caveat as the path's own fuzz cases)
+        assert np.allclose(H, H_ref, rtol=1e-5, atol=1e-7), np.abs(H - H_ref).max()
