@@ -10,15 +10,36 @@
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// Effective shader clock during a kernel: clock64() (s_memtime, shader clock) against
+// wall_clock64() (s_memrealtime, constant 100 MHz), taken by one lane around its loop.
+__device__ unsigned long long g_probe[2];
+struct ClockProbe {
+    long long c0, w0;
+    __device__ ClockProbe() : c0(clock64()), w0(wall_clock64()) {}
+    __device__ void stop() const {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            g_probe[0] = (unsigned long long)(clock64() - c0);
+            g_probe[1] = (unsigned long long)(wall_clock64() - w0);
+        }
+    }
+};
+static double probe_mhz() {
+    unsigned long long h[2] = {0, 0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_probe), sizeof(h));
+    return h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+}
+
 template <int ACC>
 __global__ __launch_bounds__(256) void k_fma(double *out, int iters, double a, double b) {
     double x[ACC];
 #pragma unroll
     for (int i = 0; i < ACC; ++i) x[i] = threadIdx.x * 1e-3 + i;
+    const ClockProbe probe;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) x[i] = fma(x[i], a, b);
     }
+    probe.stop();
     double s = 0;
 #pragma unroll
     for (int i = 0; i < ACC; ++i) s += x[i];
@@ -31,10 +52,12 @@ __global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a, 
 #pragma unroll
     for (int i = 0; i < ACC; ++i) acc[i] = double4_t{0, 0, 0, 0};
     const double av = a + threadIdx.x * 1e-6, bv = b + threadIdx.x * 1e-6;
+    const ClockProbe probe;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
     }
+    probe.stop();
     double s = 0;
 #pragma unroll
     for (int i = 0; i < ACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -50,6 +73,7 @@ __global__ __launch_bounds__(256) void k_mixed(double *out, int iters, double a,
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = threadIdx.x * 1e-3 + i;
     const double av = a + threadIdx.x * 1e-6, bv = b + threadIdx.x * 1e-6;
+    const ClockProbe probe;
     for (int it = 0; it < iters; ++it) {
         acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[0], 0, 0, 0);
 #pragma unroll
@@ -58,6 +82,7 @@ __global__ __launch_bounds__(256) void k_mixed(double *out, int iters, double a,
 #pragma unroll
         for (int i = 8; i < 16; ++i) x[i] = fma(x[i], a, b);
     }
+    probe.stop();
     double s = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += x[i];
@@ -92,27 +117,33 @@ int main() {
         constexpr int ACC = 8;
         const double ms = time_ms([&] { hipLaunchKernelGGL(k_fma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.999999, 1e-9); }, 5);
         const double flops = 2.0 * ACC * iters * (double)blocks * threads;
-        printf("v_fma_f64   (8 chains/lane, %d waves): %.3f ms  %.2f TFLOP/s\n", blocks * 4, ms, flops / ms / 1e9);
+        printf("v_fma_f64   (8 chains/lane, %d waves): %.3f ms  %.2f TFLOP/s  shader clock %.0f MHz\n", blocks * 4, ms, flops / ms / 1e9, probe_mhz());
     }
     {
         constexpr int ACC = 4;
         const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
         const double flops = 2.0 * 16 * 16 * 4 * ACC * iters * (double)blocks * (threads / 64);
-        printf("v_mfma_f64_16x16x4_f64 (4 acc/wave, %d waves): %.3f ms  %.2f TFLOP/s\n", blocks * 4, ms, flops / ms / 1e9);
+        printf("v_mfma_f64_16x16x4_f64 (4 acc/wave, %d waves): %.3f ms  %.2f TFLOP/s  shader clock %.0f MHz\n", blocks * 4, ms, flops / ms / 1e9, probe_mhz());
     }
     {
         constexpr int ACC = 1;
         const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
         const double flops = 2.0 * 16 * 16 * 4 * ACC * iters * (double)blocks * (threads / 64);
-        printf("v_mfma_f64_16x16x4_f64 (1 dependent acc/wave, 8 waves/SIMD): %.3f ms  %.2f TFLOP/s\n", ms, flops / ms / 1e9);
+        printf("v_mfma_f64_16x16x4_f64 (1 dependent acc/wave, 8 waves/SIMD): %.3f ms  %.2f TFLOP/s  shader clock %.0f MHz\n", ms, flops / ms / 1e9, probe_mhz());
     }
     {
         const int it2 = iters / 2;
         const double ms = time_ms([&] { hipLaunchKernelGGL(k_mixed, dim3(blocks), dim3(threads), 0, 0, out, it2, 0.999999, 1e-9); }, 5);
         const double f_mfma = 2.0 * 16 * 16 * 4 * 2 * it2 * (double)blocks * (threads / 64);
         const double f_valu = 2.0 * 16 * it2 * (double)blocks * threads;
-        printf("mixed 2 MFMA + 16 v_fma_f64 per iteration: %.3f ms  MFMA part %.2f + VALU part %.2f = %.2f TFLOP/s\n", ms,
-               f_mfma / ms / 1e9, f_valu / ms / 1e9, (f_mfma + f_valu) / ms / 1e9);
+        printf("mixed 2 MFMA + 16 v_fma_f64 per iteration: %.3f ms  MFMA part %.2f + VALU part %.2f = %.2f TFLOP/s  shader clock %.0f MHz\n", ms,
+               f_mfma / ms / 1e9, f_valu / ms / 1e9, (f_mfma + f_valu) / ms / 1e9, probe_mhz());
+    }
+    {
+        // light load: one wave per CU, one dependent chain
+        hipLaunchKernelGGL(k_fma<1>, dim3(prop.multiProcessorCount), dim3(64), 0, 0, out, 1 << 18, 0.999999, 1e-9);
+        (void)hipDeviceSynchronize();
+        printf("light load (1 wave per CU, dependent v_fma_f64 chain): shader clock %.0f MHz\n", probe_mhz());
     }
     hipFree(out);
     return 0;
