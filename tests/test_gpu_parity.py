@@ -584,17 +584,28 @@ def test_device_entry_points_are_graph_capturable(native, golden):
     res.warp(0)
     torch.cuda.synchronize()
     H0, out0 = res.H.clone(), res.out.clone()
+    res.equalize(0)       # the callers of the path: pre-processing and seed homography
+    res.ransac(0)
+    torch.cuda.synchronize()
+    eq0, mask0, r0 = res.eq_out.clone(), res.r_mask.clone(), res.r_res.clone()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         s = torch.cuda.current_stream().cuda_stream
+        res.equalize(s)
+        res.ransac(s)
         res.solve(s)
         res.warp(s)
     for _ in range(3):
         res.H.zero_()
         res.out.zero_()
+        res.eq_out.zero_()
+        res.r_mask.zero_()
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(res.H, H0) and torch.equal(res.out, out0)
+        assert torch.equal(res.eq_out, eq0) and torch.equal(res.r_mask, mask0) and torch.equal(res.r_res, r0)
+    from oracle import frontend_oracle as F
+    assert np.array_equal(eq0.cpu().numpy(), F.equalize_hist_image(p.img))
 
 
 def test_batched_solve_equals_separate_solves(native):
