@@ -162,6 +162,17 @@ def test_equalize_full_4k_and_properties(native):
 
 
 @pytest.mark.gpu
+def test_equalize_8k_running_sums_beyond_float32_integers(native):
+    """33 Mpixel planes: the running sums pass 2^24, so the int -> float32 conversion of
+    cv::equalizeHist rounds (to nearest even, on both sides)."""
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (4320, 7680, 3), dtype=np.uint8)
+    img[..., 2] = (img[..., 2] >> 3) + 40          # a narrow band: large bins, sums far from multiples of 2^k
+    out = native.equalize_hist(img)
+    assert np.array_equal(out, F.equalize_hist_image(img))
+
+
+@pytest.mark.gpu
 def test_equalize_device_entry_any_alignment(native):
     """Resident data, pointers at odd byte offsets (the kernels split head / 16-byte body / tail)."""
     import torch
