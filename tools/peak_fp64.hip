@@ -64,6 +64,25 @@ __global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a, 
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// the small f64 MFMA: 4 blocks of 4x4x4, one accumulator double per lane (512 flops)
+template <int ACC>
+__global__ __launch_bounds__(256) void k_mfma4(double *out, int iters, double a, double b) {
+    double acc[ACC];
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) acc[i] = 0.0;
+    const double av = a + threadIdx.x * 1e-6, bv = b + threadIdx.x * 1e-6;
+    const ClockProbe probe;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < ACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    probe.stop();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < ACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // one MFMA (1024 lane-FMAs) + 16 independent v_fma_f64 (1024 lane-FMAs) per iteration:
 // if the f64 matrix pipe and the f64 vector ALU were separate units the pair would take
 // max(), if they share the DP-FMA hardware it takes the sum.
@@ -130,6 +149,13 @@ int main() {
         const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
         const double flops = 2.0 * 16 * 16 * 4 * ACC * iters * (double)blocks * (threads / 64);
         printf("v_mfma_f64_16x16x4_f64 (1 dependent acc/wave, 8 waves/SIMD): %.3f ms  %.2f TFLOP/s  shader clock %.0f MHz\n", ms, flops / ms / 1e9, probe_mhz());
+    }
+    {
+        constexpr int ACC = 8;
+        const double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma4<ACC>, dim3(blocks), dim3(threads), 0, 0, out, iters, 0.5, 0.25); }, 5);
+        const double flops = 2.0 * 4 * 4 * 4 * 4 * ACC * iters * (double)blocks * (threads / 64);
+        printf("v_mfma_f64_4x4x4_4b_f64 (8 acc/wave, %d waves): %.3f ms  %.2f TFLOP/s  shader clock %.0f MHz\n", blocks * 4, ms,
+               flops / ms / 1e9, probe_mhz());
     }
     {
         const int it2 = iters / 2;
