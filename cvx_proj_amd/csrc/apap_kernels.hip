@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
     for (int t = 0; t < kRows; ++t) rr[t] = lut[(unsigned)min(y_first + t, y_end - 1)];
 #pragma unroll
     for (int t = 0; t < kRows; ++t) rr[t] = __builtin_amdgcn_readfirstlane(rr[t]);
+    static_assert(kRows >= 1 && kRows <= 8, "one validity bit per pixel of the strip in a 32-bit word");
     unsigned off[kRows][4];
     unsigned okbits = 0u;
     // One pass per cell row the strip touches (usually one, two when it crosses an edge): fetch
@@ -1525,13 +1526,14 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
     if (row_count == 0) return APAP_OK;  // an empty band: only the set-up kernel ran
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
-    // APAP_WARP_KERNEL (experiments): 0 = flat-order kernel, n = row strips of n rows per wave.
-    // Default 4: 3 / 4 / 5 / 6 measured within 2 % of each other at C3, 2 and 8 are 8-10 % slower.
+    // APAP_WARP_KERNEL (experiments): 0 = flat-order kernel, 2 / 4 / 8 = row strips of that many
+    // rows per wave.  Default 4: 3 / 4 / 5 / 6 measured within 2 % of each other at C3, 2 and 8 are
+    // 8-10 % slower.
     static const int warp_kernel = getenv("APAP_WARP_KERNEL") ? atoi(getenv("APAP_WARP_KERNEL")) : 4;
     // the strip kernel forms source offsets with 24-bit multiplies
     if (warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24)) {
         ProfScope prof(APAP_PROF_WARP, s);
-        const int rows = warp_kernel;  // rows per wave
+        const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;  // rows per wave: instantiated for 2, 4, 8
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
 #define APAP_LAUNCH_ROWS(R)                                                                                          \
     if (d_center)                                                                                                    \
@@ -1543,11 +1545,7 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
                            lut, final_w, final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin,    \
                            row_count)
         if (rows == 4) { APAP_LAUNCH_ROWS(4); }
-        else if (rows == 3) { APAP_LAUNCH_ROWS(3); }
-        else if (rows == 5) { APAP_LAUNCH_ROWS(5); }
-        else if (rows == 6) { APAP_LAUNCH_ROWS(6); }
         else if (rows == 8) { APAP_LAUNCH_ROWS(8); }
-        else if (rows == 16) { APAP_LAUNCH_ROWS(16); }
         else { APAP_LAUNCH_ROWS(2); }
 #undef APAP_LAUNCH_ROWS
     } else {
