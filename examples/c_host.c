@@ -1,7 +1,7 @@
 /* A host in plain C driving the engine through the C ABI alone (no Python, no torch):
  *   gcc -O2 examples/c_host.c -Iinclude -Lcvx_proj_amd -lapap_hip -Wl,-rpath,$PWD/cvx_proj_amd -lm -o c_host && ./c_host
- * Builds a small synthetic pair, runs local_homography, local_warp and the output stage,
- * prints checksums (tests/test_gpu_parity.py compares them with the Python binding's). */
+ * Builds a small synthetic pair, runs local_homography, local_warp, the output stage and the
+ * two callers of the path (equalisation, RANSAC seed homography), prints checksums (tests/test_gpu_parity.py compares them with the Python binding's). */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -45,6 +45,21 @@ int main(void) {
     for (int i = 0; i < ROWS * COLS * 9; ++i) { hs += fabs((double)H[i]); fs += fabs(flat[i]); }
     for (size_t i = 0; i < (size_t)fw * fh * 3; ++i) ps += out[i];
     printf("%s\nH_abs_sum %.9e\nflat_abs_sum %.9e\npixel_sum %llu\n", apap_version(), hs, fs, ps);
+    /* the callers of the path: pre-processing (utils.py:88) and seed homography
+     * (baseline_stitch_test.py:42) */
+    unsigned char *eq = malloc((size_t)W * Hh * 3), *mask = malloc(N);
+    rc = apap_equalize_hist(img, Hh, W, 3, eq, -1);
+    if (rc) { fprintf(stderr, "equalize_hist: %s\n", apap_last_error()); return 1; }
+    unsigned long long es = 0;
+    for (size_t i = 0; i < (size_t)W * Hh * 3; ++i) es += eq[i];
+    double Hs[9];
+    int inliers = 0;
+    rc = apap_find_homography_ransac(src, dst, N, 5.0, APAP_RANSAC_ITERATIONS, APAP_RANSAC_SEED, Hs, mask, &inliers, -1);
+    if (rc) { fprintf(stderr, "find_homography_ransac: %s\n", apap_last_error()); return 1; }
+    double ss = 0.0;
+    for (int i = 0; i < 9; ++i) ss += fabs(Hs[i]);
+    printf("equalized_sum %llu\nransac_inliers %d\nseed_H_abs_sum %.9e\n", es, inliers, ss);
+    free(eq); free(mask);
     /* error path: a mesh that does not cover the canvas is an index error, not a crash */
     mesh_h[ROWS] = fh - 10.0;
     rc = apap_local_warp(img, Hh, W, H, ROWS, COLS, mesh_w, COLS + 1, mesh_h, ROWS + 1, fw, fh, ox, oy, out, NULL, -1);

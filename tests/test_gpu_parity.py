@@ -544,6 +544,10 @@ def test_plain_c_host_uses_the_abi(native, tmp_path):
     assert np.isclose(float(vals["H_abs_sum"]), np.abs(H.astype(np.float64)).sum(), rtol=1e-6)
     assert np.isclose(float(vals["flat_abs_sum"]), np.abs(flat).sum(), rtol=1e-6)
     assert abs(int(vals["pixel_sum"]) - int(out.astype(np.uint64).sum())) <= 0.001 * int(vals["pixel_sum"])
+    assert int(vals["equalized_sum"]) == int(native.equalize_hist(img).astype(np.uint64).sum())
+    Hs, mask = native.find_homography_ransac(src, dst, 5.0)
+    assert abs(int(vals["ransac_inliers"]) - int(mask.sum())) <= 2          # keypoints may differ in the last float32 bit
+    assert np.isclose(float(vals["seed_H_abs_sum"]), np.abs(Hs).sum(), rtol=1e-4)
 
 
 def test_device_entry_points_on_a_side_stream(native, golden):
