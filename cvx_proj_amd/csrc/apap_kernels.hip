@@ -1130,9 +1130,7 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
     for (int t = 0; t < kRows; ++t) rr[t] = lut[(unsigned)min(y_first + t, y_end - 1)];
 #pragma unroll
     for (int t = 0; t < kRows; ++t) rr[t] = __builtin_amdgcn_readfirstlane(rr[t]);
-    static_assert(kRows >= 1 && kRows <= 8, "one validity bit per pixel of the strip in a 32-bit word");
     unsigned off[kRows][4];
-    unsigned okbits = 0u;
     // One pass per cell row the strip touches (usually one, two when it crosses an edge): fetch
     // that row's matrices, then do every strip row that lies in it.  All branches are wave-uniform.
     unsigned todo = (1u << kRows) - 1u;
@@ -1177,8 +1175,9 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
                 // fails t > 0).
                 const int ix = (int)tx, iy = (int)ty;
                 const bool ok = (tx > 0.0) & (ty > 0.0) & (ix < img_w) & (iy < img_h);  // no short-circuit branches
-                okbits |= ok ? (1u << (4 * t + k)) : 0u;
-                off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0u;
+                // a pixel outside the source is marked by the sign bit (the launcher sends
+                // sources of 2 GiB or more to the flat-order kernel)
+                off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
             }
         }
     }
@@ -1187,11 +1186,15 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
     for (int t = 0; t < kRows; ++t) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            // the dword at the pixel's first byte; for the image's very last pixel the dword one
+            // byte earlier, shifted (v_alignbyte_b32), so that no byte beyond the image is touched
             unsigned int v;
-            const unsigned oc = off[t][k] < last ? off[t][k] : last;
+            const unsigned o = off[t][k];
+            const unsigned oc = o < last ? o : last;
             __builtin_memcpy(&v, img + oc, 4);
-            v >>= 8 * (off[t][k] - oc);
-            px[t][k] = ((okbits >> (4 * t + k)) & 1u) ? (v & 0x00ffffffu) : 0u;
+            v = __builtin_amdgcn_alignbyte(0u, v, o - oc);
+            // v & 0xffffff & ~sign(o): v_bfe_i32 + v_bitop3_b32 (truth table a & b & ~c = 0x40)
+            px[t][k] = (unsigned)__builtin_amdgcn_bitop3_b32((int)v, 0x00ffffff, __builtin_amdgcn_sbfe((int)o, 31u, 1u), 0x40);
         }
     }
 #pragma unroll
@@ -1217,9 +1220,11 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
         uint8_t *o = out + ((size_t)(y - row_begin) * (size_t)final_w) * 3 + (unsigned)j0 * 3u;
         if (npx == 4) {
             Bytes12 v;
+            // 4 x 24 bits -> 3 dwords: one shift-or and two byte permutes (v_perm_b32 picks
+            // bytes 0-3 from its second operand, 4-7 from its first)
             v.a = px[t][0] | (px[t][1] << 24);
-            v.b = (px[t][1] >> 8) | (px[t][2] << 16);
-            v.c = (px[t][2] >> 16) | (px[t][3] << 8);
+            v.b = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
+            v.c = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
             __builtin_memcpy(o, &v, 12);  // rows start at any byte: an unaligned 12-byte store
         } else {
             for (int k = 0; k < npx; ++k) {
@@ -1531,7 +1536,9 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
     // 8-10 % slower.
     static const int warp_kernel = getenv("APAP_WARP_KERNEL") ? atoi(getenv("APAP_WARP_KERNEL")) : 4;
     // the strip kernel forms source offsets with 24-bit multiplies
-    if (warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24)) {
+    // ... and marks pixels outside the source with the sign bit of the byte offset
+    if (warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24) &&
+        (unsigned long long)img_h * (unsigned long long)img_w * 3ull < (1ull << 31)) {
         ProfScope prof(APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;  // rows per wave: instantiated for 2, 4, 8
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
