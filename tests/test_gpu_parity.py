@@ -644,3 +644,35 @@ def test_batched_solve_equals_separate_solves(native):
     for k in (0, 3):
         Hk = hip_solve(tables[k].contiguous(), denorms[k].contiguous(), verts[k].contiguous(), 0.5, 100.0)
         assert torch.equal(H2[k], Hk), k
+
+
+def test_flat_order_warp_kernel_still_matches(native, golden, tmp_path):
+    """The flat-order kernel is the fallback for sources the strip kernel does not take (a side
+    of 2^24 pixels, 2 GiB); APAP_WARP_KERNEL=0 selects it (read once per process, hence the
+    child process).  Same canvas, byte for byte, as the strip kernel and the reference."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = golden("tiny_sigma100")
+    ref_file = str(tmp_path / "ref.npy")
+    np.save(ref_file, g["warped_ref"])
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from cvx_proj_amd import _native as N\n"
+        "g = np.load(%r)\n"
+        "fw, fh, ox, oy = (int(v) for v in g['final'])\n"
+        "out, _ = N.local_warp(g['img'], g['H_ref'].copy(), g['mesh'][0], g['mesh'][1], fw, fh, ox, oy)\n"
+        "ref = np.load(%r)\n"
+        "assert np.array_equal(out, ref), int((out != ref).sum())\n"
+        "st, _ = N.local_stitch(g['img'], g['blend_other'][oy:oy + g['img'].shape[0], ox:ox + g['img'].shape[1]].copy(),\n"
+        "                       g['H_ref'].copy(), g['mesh'][0], g['mesh'][1], fw, fh, ox, oy)\n"
+        "print('flat kernel ok', out.shape, st.shape)\n"
+    ) % (root, os.path.join(root, "tests", "golden", "tiny_sigma100.npz"), ref_file)
+    env = dict(os.environ, APAP_WARP_KERNEL="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "flat kernel ok" in r.stdout, r.stdout + r.stderr
+    # and the same call in this process (strip kernel) gives the same canvas
+    fw, fh, ox, oy = (int(v) for v in g["final"])
+    out, _ = native.local_warp(g["img"], g["H_ref"].copy(), g["mesh"][0], g["mesh"][1], fw, fh, ox, oy)
+    assert np.array_equal(out, g["warped_ref"])
