@@ -236,9 +236,15 @@ def test_c1_warp_vs_reference(native, golden):
 
 
 @pytest.mark.parametrize("cfg,name", [("C2", "c2_ref"), ("C3", "c3_ref")])
-def test_full_size_warp_vs_oracle(native, golden, cfg, name):
+def test_full_size_warp_vs_oracle_and_reference(native, golden, cfg, name):
+    """Full-size canvases against the oracle pixel by pixel, and against the reference's own
+    pure-Python warp loop: its SHA-256 and every 32nd / 64th row (tests/golden/make_golden.py)."""
+    import hashlib
+    g = golden(name)
     p = config_pair(cfg)
-    check_warp(native, p.img, golden(name)["H_ref"], p.mesh, p.final_w, p.final_h, p.off_x, p.off_y)
+    w = check_warp(native, p.img, g["H_ref"], p.mesh, p.final_w, p.final_h, p.off_x, p.off_y,
+                   ref_rows=g["warped_rows"], every=int(g["warp_rows_every"]))
+    assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
 
 
 def test_identity_warp_property(native):

@@ -78,13 +78,13 @@ def test_uniform_blend(golden, name):
 @pytest.mark.parametrize("cfg,name", [("C1", "c1_ref"), ("C2", "c2_ref"), ("C3", "c3_ref")])
 def test_config_grids(golden, cfg, name):
     g = golden(name)
-    p = config_pair(cfg, with_image=(cfg == "C1"))
+    p = config_pair(cfg, with_image=(cfg in ("C1", "C2")))
     assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
     H, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
     d = O.reprojection_rmse_delta(H, g["H_ref"], p.src[:64])
     assert d.max() < 1e-6
     assert np.mean(H != g["H_ref"]) < 1e-3
-    if cfg == "C1":
+    if cfg in ("C1", "C2"):      # C3's canvas (the reference's 45 s loop) is checked on the GPU box
         every = int(g["warp_rows_every"])
         w = O.local_warp_fast(p.img, g["Hinv_ref"], p.mesh, (p.final_w, p.final_h), (p.off_x, p.off_y))
         assert np.array_equal(w[::every], g["warped_rows"])
