@@ -63,6 +63,20 @@ class Shape:
         self.shape = shape
 
 
+def reference_output_stage(local_homography):
+    """The output stage lives in the reference's ``__main__`` (apap.py:250-263), which cannot be
+    imported as a function.  Its statements are read from the reference's file at generation
+    time and executed here on ``local_homography``; nothing of them is stored in this repo."""
+    import textwrap
+    lines = open(os.path.join(REF, "apap.py")).read().splitlines()
+    start = next(i for i, ln in enumerate(lines) if ln.strip().startswith("mesh_y, mesh_x, _, _ = local_homography.shape"))
+    stop = next(i for i, ln in enumerate(lines) if i > start and "reshape(-1, 9)" in ln)
+    body = [ln for ln in lines[start:stop + 1] if not ln.strip().startswith("#")]
+    ns = {"np": np, "local_homography": local_homography.copy()}
+    exec(textwrap.dedent("\n".join(body)), ns)
+    return ns["local_homography"]
+
+
 def tiny_case(ref_apap, ref_utils, sigma, seed, name):
     """200x140 image, N=120, 5x5 mesh, non-zero offsets in x and y."""
     rng = np.random.default_rng(seed)
@@ -91,12 +105,13 @@ def tiny_case(ref_apap, ref_utils, sigma, seed, name):
     blend_other = rng.integers(0, 256, warped.shape, dtype=np.uint8)
     blend_other[rng.random(warped.shape[:2]) < 0.3] = 0
     blended = ref_utils.uniform_blend(warped, blend_other)
+    flat_ref = reference_output_stage(H_ref)
     clamped = float(np.mean(W_ref == gamma))
     np.savez_compressed(
         os.path.join(HERE, name), img=img, Hg=Hg, src=src, dst=dst, gamma=gamma, sigma=float(sigma),
         final=np.array([fw, fh, ox, oy], dtype=np.int64), mesh=mesh, vertices=vertices,
         N1=N1, N2=N2, C1=C1, C2=C2, nf1=nf1, nf2=nf2, cf1=cf1, cf2=cf2, aa=aa,
-        H_ref=H_ref, W_ref=W_ref, Hinv_ref=H_arg, warped_ref=warped,
+        H_ref=H_ref, W_ref=W_ref, Hinv_ref=H_arg, warped_ref=warped, flat_ref=flat_ref,
         blend_other=blend_other, blended_ref=blended, seed=seed)
     print(f"{name}: canvas {fw}x{fh} offsets ({ox},{oy}) clamped fraction {clamped:.3f}")
 

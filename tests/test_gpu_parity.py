@@ -305,6 +305,8 @@ def test_flatten_vs_oracle(native, golden, name):
     ref = O.invert_normalize_flatten(H)
     assert out.shape == ref.shape and out.dtype == np.float64
     assert np.array_equal(out, ref)
+    if "flat_ref" in golden(name):       # the reference's own statements (apap.py:250-263)
+        assert np.array_equal(out, golden(name)["flat_ref"])
 
 
 @pytest.mark.parametrize("name", TINY)

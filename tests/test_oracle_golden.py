@@ -111,6 +111,14 @@ def test_cell_lookup_semantics():
         O.cell_lookup(12, edges)
 
 
+@pytest.mark.parametrize("name", TINY)
+def test_output_stage_vs_reference_statements(golden, name):
+    """apap.py:250-263 executed by make_golden.py on the reference's H grid."""
+    g = golden(name)
+    out = O.invert_normalize_flatten(g["H_ref"])
+    assert out.dtype == g["flat_ref"].dtype and np.array_equal(out, g["flat_ref"])
+
+
 def test_flatten_layout():
     rng = np.random.default_rng(0)
     H = (np.eye(3) + rng.normal(0, 0.05, (2, 3, 3, 3))).astype(np.float32)
