@@ -144,9 +144,44 @@ def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_ev
     print(f"{name}: {cfg} canvas {fw}x{fh} offsets ({ox},{oy}) cells {m}x{m}")
 
 
+def keypoints_case(name="keypoints_ref.npz"):
+    """The reference's keypoints.mat reader (utils.py:55-66, imported in place) on a synthetic
+    file in the reference's directory layout: the file's four 6 x n matrices and what
+    ``get_features`` returns for every valid picture id."""
+    import tempfile
+    import scipy.io
+    import utils as ref_plain_utils          # /root/reference/pyviz/utils.py (cv2 stub already registered)
+    rng = np.random.default_rng(21)
+    mats = []
+    cells = np.empty((4, 1), dtype=object)
+    for k in range(4):
+        m = np.ones((6, 30 + 3 * k))
+        m[0:2] = rng.random((2, m.shape[1])) * [[640], [480]]
+        m[3:5] = rng.random((2, m.shape[1])) * [[640], [480]]
+        cells[k, 0] = m
+        mats.append(m)
+    out = {f"mat{k}": mats[k] for k in range(4)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "pyviz"))
+        os.makedirs(os.path.join(tmp, "diff_1", "raw_data", "case1"))
+        scipy.io.savemat(os.path.join(tmp, "diff_1", "raw_data", "case1", "keypoints.mat"), {"keypoints": cells})
+        os.chdir(os.path.join(tmp, "pyviz"))          # the reference reads ../diff_1/raw_data/case1/keypoints.mat
+        try:
+            for pic_id in (1, 2, 4, 5):
+                cp, op = ref_plain_utils.get_features(1, pic_id, 3)
+                out[f"cp{pic_id}"], out[f"op{pic_id}"] = cp, op
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: get_features for pictures 1, 2, 4, 5")
+
+
 def main():
     ref_apap, ref_utils = import_reference()
-    which = sys.argv[1:] or ["tiny", "C1", "C2"]
+    which = sys.argv[1:] or ["tiny", "keypoints", "C1", "C2"]
+    if "keypoints" in which:
+        keypoints_case()
     if "tiny" in which:
         tiny_case(ref_apap, ref_utils, 100.0, 11, "tiny_sigma100.npz")
         tiny_case(ref_apap, ref_utils, 6.0, 12, "tiny_sigma6.npz")

@@ -117,6 +117,23 @@ def test_get_features_indexing(tmp_path):
         U.get_features(1, 3, 3, root=str(tmp_path))
 
 
+def test_get_features_vs_reference(tmp_path, golden):
+    """The reference's own reader (utils.py:55-66, run by tests/golden/make_golden.py) on the same
+    keypoints.mat: same arrays for every valid picture id, same error for the centre id."""
+    import scipy.io
+    from cvx_proj_amd import utils as U
+    g = golden("keypoints_ref")
+    cells = np.empty((4, 1), dtype=object)
+    for k in range(4):
+        cells[k, 0] = g[f"mat{k}"]
+    os.makedirs(tmp_path / "case1")
+    scipy.io.savemat(tmp_path / "case1" / "keypoints.mat", {"keypoints": cells})
+    for pic_id in (1, 2, 4, 5):
+        cp, op = U.get_features(1, pic_id, 3, root=str(tmp_path))
+        assert cp.dtype == g[f"cp{pic_id}"].dtype and np.array_equal(cp, g[f"cp{pic_id}"])
+        assert np.array_equal(op, g[f"op{pic_id}"])
+
+
 def test_imread_is_bgr_and_paths(tmp_path):
     from cvx_proj_amd import utils as U
     imgs, _ = write_case(str(tmp_path))
