@@ -116,12 +116,12 @@ def tiny_case(ref_apap, ref_utils, sigma, seed, name):
     print(f"{name}: canvas {fw}x{fh} offsets ({ox},{oy}) clamped fraction {clamped:.3f}")
 
 
-def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_every=1):
+def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_every=1, seed_offset=0):
     """A BASELINE.json config: full H grid from the reference; for the warp, a SHA-256 of
     the full canvas plus every ``warp_rows_every``-th row."""
     sys.path.insert(0, REPO)
     from cvx_proj_amd.synth import config_pair
-    p = config_pair(cfg)
+    p = config_pair(cfg, with_image=bool(warp_rows_every), seed_offset=seed_offset)
     fw, fh, ox, oy = ref_utils.final_size(Shape(p.shape), Shape(p.shape), p.Hg)
     assert (fw, fh, ox, oy) == (p.final_w, p.final_h, p.off_x, p.off_y)
     m = p.vertices.shape[0]
@@ -192,6 +192,10 @@ def main():
         config_case(ref_apap, ref_utils, "C2", "c2_ref.npz", warp_rows_every=32)
     if "C3" in which:
         config_case(ref_apap, ref_utils, "C3", "c3_ref.npz", warp_rows_every=64)
+    if "C5" in which:
+        # two of the 64 independent pairs of C5 (seed 6400 + k), ~12 s each in the reference's loop
+        for k in (0, 1):
+            config_case(ref_apap, ref_utils, "C5", f"c5_ref_k{k}.npz", warp_rows_every=0, seed_offset=k)
     if "C4" in which:
         # ~7 minutes in the reference's Python loop; only every 8th mesh row is kept (720 KB)
         config_case(ref_apap, ref_utils, "C4", "c4_ref_rows8.npz", warp_rows_every=0, keep_rows_every=8)

@@ -351,8 +351,9 @@ def test_c4_full_size_solve_vs_oracle_subset(native, golden):
     assert jump.max() < 50 * np.median(jump) + 1e-6
 
 
-def test_c5_pairs_through_driver(native):
-    """Batch of independent 4K pairs (config C5) through cvx_proj_amd.dist.solve_pairs on one rank."""
+def test_c5_pairs_through_driver(native, golden):
+    """Batch of independent 4K pairs (config C5) through cvx_proj_amd.dist.solve_pairs on one
+    rank; pairs 0 and 1 against the reference's own grids, all four against the oracle."""
     import torch
     from cvx_proj_amd.dist import solve_pairs
     pairs = [config_pair("C5", with_image=False, seed_offset=k) for k in range(4)]
@@ -361,6 +362,10 @@ def test_c5_pairs_through_driver(native):
     for k, (g, p) in enumerate(zip(grids, pairs)):
         H_ref, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
         assert report(f"C5 pair {k}", g, H_ref, p.src[:128]).max() < RMSE_BAR
+        if k < 2:
+            ref = golden(f"c5_ref_k{k}")["H_ref"]
+            assert report(f"C5 pair {k} vs reference", g, ref, p.src[:128]).max() < RMSE_BAR
+            assert np.array_equal(g, ref)
     assert not np.array_equal(grids[0], grids[1])
 
 

@@ -92,6 +92,17 @@ def test_config_grids(golden, cfg, name):
         assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
 
 
+@pytest.mark.parametrize("k", [0, 1])
+def test_c5_pairs_vs_reference(golden, k):
+    """Two of C5's 64 independent pairs (seed 6400 + k), full 100 x 100 grids from the reference."""
+    g = golden(f"c5_ref_k{k}")
+    p = config_pair("C5", with_image=False, seed_offset=k)
+    assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
+    H, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
+    assert O.reprojection_rmse_delta(H, g["H_ref"], p.src[:64]).max() < 1e-6
+    assert np.mean(H != g["H_ref"]) < 1e-3
+
+
 def test_c4_rows_vs_reference(golden):
     """Every 8th mesh row of the 8K / 5000-keypoint / 400 x 400 grid, from the reference."""
     g = golden("c4_ref_rows8")
