@@ -144,6 +144,41 @@ def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_ev
     print(f"{name}: {cfg} canvas {fw}x{fh} offsets ({ox},{oy}) cells {m}x{m}")
 
 
+EDGE_CASES = [   # (n, mesh rows, mesh cols, gamma, sigma)
+    (4, 2, 3, 0.5, 100.0),       # fewer than 5 keypoints: the thin SVD has 8 rows of V^T
+    (5, 3, 2, 0.5, 100.0),
+    (6, 1, 1, 0.5, 30.0),        # a single cell
+    (40, 2, 9, 0.0, 30.0),       # no clamp
+    (40, 7, 1, -1.0, 30.0),      # a negative gamma never clamps
+    (40, 3, 4, 1.5, 50.0),       # everything clamped above 1
+    (40, 4, 3, 0.9, 8.0),
+    (40, 3, 3, 0.5, 0.5),        # sigma so small that every weight is gamma
+    (40, 2, 2, 0.5, 1e4),        # all weights ~1
+    (300, 5, 6, 0.5, 12.0),
+]
+
+
+def edge_cases(ref_apap, name="edge_ref.npz"):
+    """Small inputs on the corners of the parameter space, through the reference's
+    ``APAP.local_homography``: ragged meshes, n = 4..6, gamma in {0, <0, >1}, extreme sigma."""
+    out = {"count": len(EDGE_CASES)}
+    for k, (n, rows, cols, gamma, sigma) in enumerate(EDGE_CASES):
+        rng = np.random.default_rng(500 + k)
+        w, h = 640, 480
+        Hg = np.array([[1.01, 0.02, 7.0], [-0.015, 0.99, -4.0], [2e-5, -1e-5, 1.0]])
+        src = (rng.random((n, 2)) * [w, h]).astype(np.float32)
+        q = np.concatenate([src.astype(np.float64), np.ones((n, 1))], axis=1) @ Hg.T
+        dst = (q[:, :2] / q[:, 2:3] + rng.normal(0, 0.6, (n, 2))).astype(np.float32)
+        verts = np.stack(np.meshgrid(np.linspace(20, w - 20, cols), np.linspace(15, h - 15, rows)), axis=-1)
+        eng = ref_apap.APAP(gamma, sigma, [w, h], [0, 0])
+        with np.errstate(all="ignore"):
+            H, W = eng.local_homography(src, dst, verts)
+        out.update({f"src{k}": src, f"dst{k}": dst, f"verts{k}": verts, f"par{k}": np.array([gamma, sigma]),
+                    f"H{k}": H, f"W{k}": W})
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: {len(EDGE_CASES)} edge cases")
+
+
 def keypoints_case(name="keypoints_ref.npz"):
     """The reference's keypoints.mat reader (utils.py:55-66, imported in place) on a synthetic
     file in the reference's directory layout: the file's four 6 x n matrices and what
@@ -179,9 +214,11 @@ def keypoints_case(name="keypoints_ref.npz"):
 
 def main():
     ref_apap, ref_utils = import_reference()
-    which = sys.argv[1:] or ["tiny", "keypoints", "C1", "C2"]
+    which = sys.argv[1:] or ["tiny", "keypoints", "edge", "C1", "C2"]
     if "keypoints" in which:
         keypoints_case()
+    if "edge" in which:
+        edge_cases(ref_apap)
     if "tiny" in which:
         tiny_case(ref_apap, ref_utils, 100.0, 11, "tiny_sigma100.npz")
         tiny_case(ref_apap, ref_utils, 6.0, 12, "tiny_sigma6.npz")

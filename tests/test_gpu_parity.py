@@ -462,6 +462,20 @@ def test_gamma_sigma_ranges_vs_oracle(native, gamma, sigma):
     assert report(f"gamma={gamma} sigma={sigma}", H, H_ref, p.src).max() < RMSE_BAR
 
 
+@pytest.mark.parametrize("k", range(10))
+def test_edge_cases_vs_reference(native, golden, variant, k):
+    """The same corners of the parameter space against the reference's own outputs."""
+    g = golden("edge_ref")
+    gamma, sigma = (float(v) for v in g[f"par{k}"])
+    H, W = native.local_homography(g[f"src{k}"], g[f"dst{k}"], g[f"verts{k}"], gamma, sigma)
+    assert np.allclose(W, g[f"W{k}"], rtol=1e-14, atol=1e-300)
+    d = report(f"edge case {k}", H, g[f"H{k}"], g[f"src{k}"])
+    n = len(g[f"src{k}"])
+    # n = 4: an exact null vector, the smallest singular value is ~0 for every weight (see
+    # test_ragged_shapes_vs_oracle); otherwise the parity bar
+    assert d.max() < (1e-3 if n == 4 else RMSE_BAR)
+
+
 def test_all_weights_underflow_does_not_hang(native):
     """sigma so small that exp underflows to 0 and gamma = 0: the normal matrix is exactly
     zero; the solver must terminate (Jacobi fallback on a zero matrix) - values are whatever

@@ -92,6 +92,19 @@ def test_config_grids(golden, cfg, name):
         assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
 
 
+@pytest.mark.parametrize("k", range(10))
+def test_edge_cases_vs_reference(golden, k):
+    """Corners of the parameter space run through the reference itself (make_golden.py edge):
+    n = 4..6 (thin SVD), 1 x 1 and ragged meshes, gamma in {0, <0, >1}, extreme sigma."""
+    g = golden("edge_ref")
+    gamma, sigma = (float(v) for v in g[f"par{k}"])
+    with np.errstate(all="ignore"):
+        H, W = O.local_homography_loop(g[f"src{k}"], g[f"dst{k}"], g[f"verts{k}"], gamma, sigma)
+        Hf, _ = O.local_homography_fast(g[f"src{k}"], g[f"dst{k}"], g[f"verts{k}"], gamma, sigma)
+    assert np.array_equal(H, g[f"H{k}"]) and np.array_equal(W, g[f"W{k}"])
+    assert O.reprojection_rmse_delta(Hf, g[f"H{k}"], g[f"src{k}"]).max() < 1e-6
+
+
 @pytest.mark.parametrize("k", [0, 1])
 def test_c5_pairs_vs_reference(golden, k):
     """Two of C5's 64 independent pairs (seed 6400 + k), full 100 x 100 grids from the reference."""
