@@ -179,6 +179,40 @@ def edge_cases(ref_apap, name="edge_ref.npz"):
     print(f"{name}: {len(EDGE_CASES)} edge cases")
 
 
+WARP_EDGE_CASES = [   # (image w, h, mesh rows, mesh cols, canvas w, h, offset x, y, perspective)
+    (37, 23, 1, 1, 41, 29, 3, 2, 0.0),          # a single cell
+    (64, 48, 9, 13, 71, 50, 5, 1, 2e-3),        # strong perspective: part of the canvas maps outside
+    (50, 40, 6, 40, 3, 45, 0, 4, 0.0),          # a canvas narrower than one 4-pixel group
+    (33, 90, 30, 2, 37, 95, 2, 3, -1e-3),       # cells one pixel tall
+    (16, 16, 4, 4, 16, 16, 0, 0, 0.0),          # canvas = image, zero offsets
+]
+
+
+def warp_edge_cases(ref_apap, ref_utils, name="warp_edge_ref.npz"):
+    """Small warps on the corners of the geometry, through the reference's ``APAP.local_warp``."""
+    out = {"count": len(WARP_EDGE_CASES)}
+    for k, (w, h, rows, cols, fw, fh, ox, oy, persp) in enumerate(WARP_EDGE_CASES):
+        rng = np.random.default_rng(700 + k)
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        H = np.empty((rows, cols, 3, 3), dtype=np.float32)
+        for i in range(rows):
+            for j in range(cols):
+                H[i, j] = np.array([[1.0 + 0.01 * rng.normal(), 0.02 * rng.normal(), ox + rng.normal()],
+                                    [0.02 * rng.normal(), 1.0 + 0.01 * rng.normal(), oy + rng.normal()],
+                                    [persp * rng.random(), persp * rng.random(), 1.0]], dtype=np.float32)
+        mesh = ref_utils.get_mesh((fw, fh), max(rows, cols) + 1)       # the reference's square mesh ...
+        mesh_w = np.linspace(0, fw, cols + 1)                              # ... and a ragged one
+        mesh_h = np.linspace(0, fh, rows + 1)
+        eng = ref_apap.APAP(0.5, 100.0, [fw, fh], [ox, oy])
+        H_arg = H.copy()
+        warped = eng.local_warp(img, H_arg, (mesh_w, mesh_h), False)
+        del mesh
+        out.update({f"img{k}": img, f"H{k}": H, f"mesh_w{k}": mesh_w, f"mesh_h{k}": mesh_h,
+                    f"geo{k}": np.array([fw, fh, ox, oy]), f"Hinv{k}": H_arg, f"warped{k}": warped})
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: {len(WARP_EDGE_CASES)} warp edge cases")
+
+
 def keypoints_case(name="keypoints_ref.npz"):
     """The reference's keypoints.mat reader (utils.py:55-66, imported in place) on a synthetic
     file in the reference's directory layout: the file's four 6 x n matrices and what
@@ -219,6 +253,7 @@ def main():
         keypoints_case()
     if "edge" in which:
         edge_cases(ref_apap)
+        warp_edge_cases(ref_apap, ref_utils)
     if "tiny" in which:
         tiny_case(ref_apap, ref_utils, 100.0, 11, "tiny_sigma100.npz")
         tiny_case(ref_apap, ref_utils, 6.0, 12, "tiny_sigma6.npz")

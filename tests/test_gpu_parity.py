@@ -247,6 +247,16 @@ def test_full_size_warp_vs_oracle_and_reference(native, golden, cfg, name):
     assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
 
 
+@pytest.mark.parametrize("k", range(5))
+def test_warp_edge_cases_vs_reference(native, golden, k):
+    """The same corners of the geometry against the reference's own canvases and inverses."""
+    g = golden("warp_edge_ref")
+    fw, fh, ox, oy = (int(v) for v in g[f"geo{k}"])
+    out, hinv = native.local_warp(g[f"img{k}"], g[f"H{k}"].copy(), g[f"mesh_w{k}"], g[f"mesh_h{k}"], fw, fh, ox, oy)
+    assert np.array_equal(hinv, g[f"Hinv{k}"])
+    assert np.array_equal(out, g[f"warped{k}"])
+
+
 def test_identity_warp_property(native):
     """All-identity cells, zero offsets: the canvas is the image, except row 0 and
     column 0, which the strict `0 < t` test of apap.py:214 leaves black."""

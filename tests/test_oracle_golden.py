@@ -105,6 +105,19 @@ def test_edge_cases_vs_reference(golden, k):
     assert O.reprojection_rmse_delta(Hf, g[f"H{k}"], g[f"src{k}"]).max() < 1e-6
 
 
+@pytest.mark.parametrize("k", range(5))
+def test_warp_edge_cases_vs_reference(golden, k):
+    """Corners of the warp geometry run through the reference's ``local_warp``: one cell, strong
+    perspective, a canvas narrower than 4 pixels, one-pixel cells, canvas = image."""
+    g = golden("warp_edge_ref")
+    fw, fh, ox, oy = (int(v) for v in g[f"geo{k}"])
+    mesh = (g[f"mesh_w{k}"], g[f"mesh_h{k}"])
+    hinv = O.invert_cells_f32(g[f"H{k}"])
+    assert np.array_equal(hinv, g[f"Hinv{k}"])
+    assert np.array_equal(O.local_warp_fast(g[f"img{k}"], hinv, mesh, (fw, fh), (ox, oy)), g[f"warped{k}"])
+    assert np.array_equal(O.local_warp_loop(g[f"img{k}"], g[f"H{k}"].copy(), mesh, (fw, fh), (ox, oy)), g[f"warped{k}"])
+
+
 @pytest.mark.parametrize("k", [0, 1])
 def test_c5_pairs_vs_reference(golden, k):
     """Two of C5's 64 independent pairs (seed 6400 + k), full 100 x 100 grids from the reference."""
