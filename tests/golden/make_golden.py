@@ -213,6 +213,32 @@ def warp_edge_cases(ref_apap, ref_utils, name="warp_edge_ref.npz"):
     print(f"{name}: {len(WARP_EDGE_CASES)} warp edge cases")
 
 
+def prepare_large_n(ref_apap, name="prepare_ref.npz"):
+    """The once-per-pair set-up (apap.py:35-119) through the reference for keypoint counts beyond
+    numpy's 8192-element reduction buffer, where the order of the float32 sums changes: the four
+    3 x 3 matrices in full, SHA-256 of the normalised points and of the DLT rows."""
+    out = {}
+    sizes = (8192, 8193, 20001, 50000)
+    for n in sizes:
+        rng = np.random.default_rng(900 + n)
+        src = (rng.random((n, 2)) * [3840, 2160]).astype(np.float32)
+        dst = (src + rng.normal(0, 5, (n, 2)) + [30, -20]).astype(np.float32)
+        eng = ref_apap.APAP(0.5, 100.0, [1, 1], [0, 0])
+        N1, nf1 = eng.getNormalize2DPts(src)
+        N2, nf2 = eng.getNormalize2DPts(dst)
+        C1 = eng.getConditionerFromPts(nf1)
+        C2 = eng.getConditionerFromPts(nf2)
+        cf1 = eng.point_normalize(nf1, C1)
+        cf2 = eng.point_normalize(nf2, C2)
+        aa = eng.matrix_generate(n, cf1, cf2)
+        sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)  # noqa: E731
+        out.update({f"N1_{n}": N1, f"N2_{n}": N2, f"C1_{n}": C1, f"C2_{n}": C2, f"nf1_{n}": sha(nf1), f"nf2_{n}": sha(nf2),
+                    f"cf1_{n}": sha(cf1), f"cf2_{n}": sha(cf2), f"aa_{n}": sha(aa), f"aa_dtype_{n}": np.array(str(aa.dtype))})
+    out["sizes"] = np.array(sizes)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: set-up for n in {sizes}")
+
+
 def keypoints_case(name="keypoints_ref.npz"):
     """The reference's keypoints.mat reader (utils.py:55-66, imported in place) on a synthetic
     file in the reference's directory layout: the file's four 6 x n matrices and what
@@ -248,9 +274,11 @@ def keypoints_case(name="keypoints_ref.npz"):
 
 def main():
     ref_apap, ref_utils = import_reference()
-    which = sys.argv[1:] or ["tiny", "keypoints", "edge", "C1", "C2"]
+    which = sys.argv[1:] or ["tiny", "keypoints", "edge", "prepare", "C1", "C2"]
     if "keypoints" in which:
         keypoints_case()
+    if "prepare" in which:
+        prepare_large_n(ref_apap)
     if "edge" in which:
         edge_cases(ref_apap)
         warp_edge_cases(ref_apap, ref_utils)

@@ -25,6 +25,28 @@ def test_c_prepare_matches_reference_vectors(native, golden, name):
     assert np.array_equal(q["iN2"], np.linalg.inv(g["N2"]))
 
 
+def test_prepare_beyond_numpy_reduction_buffer_vs_reference(native, golden):
+    """n = 8192, 8193, 20001, 50000 through the reference's own set-up functions
+    (tests/golden/make_golden.py prepare): the oracle and the C host code give the same four
+    matrices and the same normalised points and DLT rows, bit for bit."""
+    import hashlib
+    g = golden("prepare_ref")
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)  # noqa: E731
+    for n in (int(v) for v in g["sizes"]):
+        rng = np.random.default_rng(900 + n)
+        src = (rng.random((n, 2)) * [3840, 2160]).astype(np.float32)
+        dst = (src + rng.normal(0, 5, (n, 2)) + [30, -20]).astype(np.float32)
+        p = O.prepare(src, dst)
+        q = native.host_prepare(src, dst)
+        for who, r in (("oracle", p), ("C host", q)):
+            for k in ("N1", "N2", "C1", "C2"):
+                assert np.array_equal(r[k], g[f"{k}_{n}"]), (who, n, k)
+            for k in ("nf1", "nf2", "cf1", "cf2"):
+                assert np.array_equal(sha(r[k]), g[f"{k}_{n}"]), (who, n, k)
+        assert np.array_equal(sha(p["aa"]), g[f"aa_{n}"])
+        assert np.array_equal(sha(native.host_dlt_rows(q["cf1"], q["cf2"])), g[f"aa_{n}"])
+
+
 def test_c_prepare_matches_oracle_random(native):
     rng = np.random.default_rng(3)
     # beyond 8192 numpy's reductions run in buffer-sized pieces: cover that regime too
