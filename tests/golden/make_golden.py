@@ -279,6 +279,15 @@ def main():
         keypoints_case()
     if "prepare" in which:
         prepare_large_n(ref_apap)
+        # the whole local_homography with 20 001 keypoints on a 6 x 6 mesh (the regime where the
+        # summation order of the conditioner decides the last float32 bits of the grid)
+        sys.path.insert(0, REPO)
+        from cvx_proj_amd.synth import synth_pair
+        p = synth_pair(1920, 1080, 20001, 6, seed=12, with_image=False)
+        eng = ref_apap.APAP(p.gamma, p.sigma, [p.final_w, p.final_h], [p.off_x, p.off_y])
+        H_ref, _ = eng.local_homography(p.src, p.dst, p.vertices)
+        np.savez_compressed(os.path.join(HERE, "n20001_ref.npz"), H_ref=H_ref)
+        print("n20001_ref.npz: 6 x 6 grid from 20001 keypoints")
     if "edge" in which:
         edge_cases(ref_apap)
         warp_edge_cases(ref_apap, ref_utils)

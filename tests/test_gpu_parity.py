@@ -495,13 +495,17 @@ def test_all_weights_underflow_does_not_hang(native):
     assert (W == 0).all() and H.shape == (3, 3, 3, 3)
 
 
-def test_many_keypoints_and_splits(native, variant):
-    """n = 20 000 (more keypoints than any config; exercises the chunk loop, partial last
-    chunk and several grid-level splits on a small mesh)."""
+def test_many_keypoints_and_splits(native, golden, variant):
+    """n = 20 001 (more keypoints than any config; exercises the chunk loop, partial last
+    chunk and several grid-level splits on a small mesh) against the oracle and against the
+    reference's own grid."""
     p = synth_pair(1920, 1080, 20001, 6, seed=12)
     H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
     H_ref, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
     assert report("n=20001", H, H_ref, p.src[:256]).max() < RMSE_BAR
+    ref = golden("n20001_ref")["H_ref"]
+    assert report("n=20001 vs reference", H, ref, p.src[:256]).max() < RMSE_BAR
+    assert np.array_equal(H, ref)
 
 
 def test_mesh_with_more_edges_than_the_lds_lookup_holds(native):

@@ -105,6 +105,14 @@ def test_edge_cases_vs_reference(golden, k):
     assert O.reprojection_rmse_delta(Hf, g[f"H{k}"], g[f"src{k}"]).max() < 1e-6
 
 
+def test_many_keypoints_vs_reference(golden):
+    """20 001 keypoints, 6 x 6 mesh, from the reference."""
+    from cvx_proj_amd.synth import synth_pair
+    p = synth_pair(1920, 1080, 20001, 6, seed=12, with_image=False)
+    H, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
+    assert np.array_equal(H, golden("n20001_ref")["H_ref"])
+
+
 @pytest.mark.parametrize("k", range(5))
 def test_warp_edge_cases_vs_reference(golden, k):
     """Corners of the warp geometry run through the reference's ``local_warp``: one cell, strong
