@@ -5,10 +5,20 @@ Run in the build container only (``/root/reference`` must be mounted):
 
     python tests/golden/make_golden.py
 
-What it does: imports ``/root/reference/pyviz/apap.py`` and ``apap_utils.py`` in place
-(nothing is copied), feeds them seeded synthetic inputs, and stores inputs + the
+What it does: imports ``/root/reference/pyviz/apap.py``, ``apap_utils.py`` and ``utils.py`` in
+place (nothing is copied), feeds them seeded synthetic inputs, and stores inputs + the
 reference's outputs as small ``.npz`` files.  The committed ``.npz`` files are data; this
 script is how they were made.
+
+    python tests/golden/make_golden.py [tiny] [keypoints] [edge] [prepare] [C1] [C2] [C3] [C4] [C5]
+
+    tiny        tiny_sigma100 / tiny_sigma6: every intermediate of a 5 x 5 case, warp, blend, output stage
+    keypoints   keypoints_ref: utils.get_features on a synthetic keypoints.mat
+    edge        edge_ref (10 corners of the parameter space), warp_edge_ref (5 corners of the warp geometry)
+    prepare     prepare_ref (set-up at n = 8192 ... 50000), n20001_ref (a 6 x 6 grid from 20001 keypoints)
+    C1 C2 C3    full H grids + the warped canvas (SHA-256 and sampled rows) of the BASELINE.json configs
+    C4          every 8th mesh row of the 400 x 400 grid (~7 minutes of the reference's loop)
+    C5          two of the 64 independent pairs
 
 Two things the reference needs that this image lacks, and how they are served:
 * ``cv2`` (OpenCV) is not installed.  ``apap.py`` uses exactly one OpenCV function on
