@@ -534,7 +534,7 @@ constexpr int kMaxSweeps = 15;
 // For 2n >= 9 that is the smallest eigenvalue of A^T W^2 A (pick_rank 0); for fewer rows
 // the thin V^T has only 2n rows and its last one belongs to the (9 - 2n)-th smallest
 // eigenvalue.  Rank = number of strictly smaller diagonal entries, ties broken by index.
-__device__ __forceinline__ void jacobi_eigvec(double (&a)[45], int pick_rank, double (&h)[9]) {
+__device__ __forceinline__ double jacobi_eigvec(double (&a)[45], int pick_rank, double (&h)[9]) {
     double v[81];
 #pragma unroll
     for (int k = 0; k < 81; ++k) v[k] = (k % 10 == 0) ? 1.0 : 0.0;
@@ -553,6 +553,7 @@ __device__ __forceinline__ void jacobi_eigvec(double (&a)[45], int pick_rank, do
         if (__all(done)) break;
     }
     int best = 0;
+    double lam0 = 0.0, lam1 = 0.0;  // the two smallest eigenvalues
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         int rank = 0;
@@ -564,6 +565,8 @@ __device__ __forceinline__ void jacobi_eigvec(double (&a)[45], int pick_rank, do
             }
         }
         best = (rank == pick_rank) ? i : best;
+        lam0 = (rank == 0) ? a[tri(i, i)] : lam0;
+        lam1 = (rank == 1) ? a[tri(i, i)] : lam1;
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -572,6 +575,7 @@ __device__ __forceinline__ void jacobi_eigvec(double (&a)[45], int pick_rank, do
         for (int c = 1; c < 9; ++c) x = (best == c) ? v[9 * k + c] : x;
         h[k] = x;
     }
+    return lam1 - lam0;
 }
 
 // Smallest eigenvector by inverse iteration on an in-register L D L^T factorisation
@@ -585,7 +589,7 @@ constexpr int kMaxInvIt = 12;
 
 __host__ __device__ constexpr int low(int i, int j) { return i * (i - 1) / 2 + j; }  // strict lower, i > j
 
-__device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double (&h)[9]) {
+__device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double (&h)[9], double &rho) {
     double l[36], d[9], rd[9];  // unit lower factor, pivots and their reciprocals
     bool ok = true;
 #pragma unroll
@@ -617,6 +621,7 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = 1.0 / 3.0;
     bool done = false;
+    double vMv = 1.0;  // v^T M^-1 v of the last step: 1 / vMv >= lambda_min (Rayleigh quotient of M^-1)
     for (int it = 0; it < kMaxInvIt; ++it) {
         double y[9];
 #pragma unroll
@@ -644,6 +649,7 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
             dot = fma(y[i], v[i], dot);
         }
         const double scale = copysign(1.0, dot) / sqrt(nrm2);
+        vMv = fabs(dot);
         double change = 0.0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
@@ -656,7 +662,197 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) h[k] = v[k];
+    rho = 1.0 / vMv;
     return ok && done;
+}
+
+// ---- conditioning guard -----------------------------------------------------------
+// The reference takes the SVD of the weighted 2n x 9 matrix W A itself (apap.py:159-161); K1/K2
+// solve A^T W^2 A, whose eigenvector v9 carries an error ~ eps * lambda_1 / (lambda_8 - lambda_9)
+// - the SQUARE of what the SVD's eps * sigma_1 / (sigma_8 - sigma_9) is.  On the Hartley-normalised
+// systems of image data (lambda_8 - lambda_9) / trace sits at 1.5e-2 (C1-C5, every golden case); with
+// gamma = 0 and sigma of a few pixels the weights span 10+ orders of magnitude and it falls to
+// 1e-7 ... 1e-20 (soak seeds 544, 659, 795, 814, 883: hundreds of pixels off).  A cell whose gap is
+// below kGapTol * trace is re-solved from the weighted rows themselves (qr_resolve below).
+constexpr double kGapTol = 1e-4;  // normal-equation error ~ 50 eps / kGapTol = 1e-10 relative at the threshold
+
+__device__ __forceinline__ double rcp_fast(double x) {  // ~2^-46: only signs of pivots are used
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// Number of eigenvalues of A^T W^2 A below mu (Sylvester's law of inertia: the negative pivots of
+// an L D L^T of M - mu I), using the block structure [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]:
+// one 3x3 factorisation serves both S0 blocks, then the 3x3 Schur complement.  ~100 instructions.
+// A zero or NaN pivot counts as negative (the caller then takes the careful path).
+__device__ __forceinline__ int count_eigs_below(const double (&m)[kMoments], double mu) {
+    const double s00 = m[0] - mu, s01 = m[1], s02 = m[2], s11 = m[3] - mu, s12 = m[4], s22 = m[5] - mu;
+    const double p0 = s00, r0 = rcp_fast(p0);
+    const double l10 = s01 * r0, l20 = s02 * r0;
+    const double p1 = fma(-l10, s01, s11), r1 = rcp_fast(p1);
+    const double l21 = fma(-l20, s01, s12) * r1;
+    const double p2 = fma(-l21 * l21, p1, fma(-l20, s02, s22)), r2 = rcp_fast(p2);
+    int neg = 2 * ((p0 > 0.0 ? 0 : 1) + (p1 > 0.0 ? 0 : 1) + (p2 > 0.0 ? 0 : 1));
+    double c00 = m[24] - mu, c01 = m[25], c02 = m[26], c11 = m[27] - mu, c12 = m[28], c22 = m[29] - mu;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {  // S1 = m[6..14], S2 = m[15..23], row-major 3x3
+        double y[3][3], z[3][3];   // y = L^-1 S (forward substitution per column), z = D^-1 y
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double t0 = m[6 + 9 * b + j], t1 = m[9 + 9 * b + j], t2 = m[12 + 9 * b + j];
+            y[0][j] = t0;
+            y[1][j] = fma(-l10, t0, t1);
+            y[2][j] = fma(-l21, y[1][j], fma(-l20, t0, t2));
+            z[0][j] = y[0][j] * r0; z[1][j] = y[1][j] * r1; z[2][j] = y[2][j] * r2;
+        }
+#define APAP_SCHUR(i, j) fma(-y[2][i], z[2][j], fma(-y[1][i], z[1][j], -y[0][i] * z[0][j]))
+        c00 += APAP_SCHUR(0, 0); c01 += APAP_SCHUR(0, 1); c02 += APAP_SCHUR(0, 2);
+        c11 += APAP_SCHUR(1, 1); c12 += APAP_SCHUR(1, 2); c22 += APAP_SCHUR(2, 2);
+#undef APAP_SCHUR
+    }
+    const double q0 = c00, k0 = rcp_fast(q0);
+    const double g10 = c01 * k0, g20 = c02 * k0;
+    const double q1 = fma(-g10, c01, c11), k1 = rcp_fast(q1);
+    const double g21 = fma(-g20, c01, c12) * k1;
+    const double q2 = fma(-g21 * g21, q1, fma(-g20, c02, c22));
+    neg += (q0 > 0.0 ? 0 : 1) + (q1 > 0.0 ? 0 : 1) + (q2 > 0.0 ? 0 : 1);
+    return neg;
+}
+
+// One Givens rotation of the row-insertion QR: eliminates r[K] against R[K][K] and updates the
+// rest of both rows.  The hypotenuse is formed on operands scaled by a power of two, so weights
+// down to the denormal range neither underflow in the squares nor lose the rotation's orthogonality.
+template <int K>
+__device__ __forceinline__ void givens_insert(double (&R)[45], double (&r)[9]) {
+    const double a = R[tri(K, K)], b = r[K];
+    const double big = fmax(fabs(a), fabs(b));
+    const bool rot = (b != 0.0) && (big < 1.797e308);  // false for NaN/inf rows: they are dropped
+    const int e = rot ? __builtin_amdgcn_frexp_exp(big) : 0;
+    const double sa = __builtin_ldexp(a, -e), sb = __builtin_ldexp(b, -e);
+    const double t = sqrt(fma(sa, sa, sb * sb));
+    const double c = rot ? sa / t : 1.0, s = rot ? sb / t : 0.0;
+    R[tri(K, K)] = rot ? __builtin_ldexp(t, e) : a;
+#pragma unroll
+    for (int j = K + 1; j < 9; ++j) {
+        const double x = R[tri(K, j)], y = r[j];
+        R[tri(K, j)] = fma(c, x, s * y);
+        r[j] = fma(c, y, -(s * x));
+    }
+    r[K] = 0.0;
+}
+
+template <int P, int Q>
+__device__ __forceinline__ bool hestenes_rotate(double (&G)[81], double tol) {
+    double alpha = 0.0, beta = 0.0, gam = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        alpha = fma(G[9 * i + P], G[9 * i + P], alpha);
+        beta = fma(G[9 * i + Q], G[9 * i + Q], beta);
+        gam = fma(G[9 * i + P], G[9 * i + Q], gam);
+    }
+    const bool rot = fabs(gam) > tol * sqrt(alpha * beta);  // false for gam == 0 and for NaN
+    const double zeta = (beta - alpha) / (2.0 * gam);
+    double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+    t = rot ? t : 0.0;
+    const double c = 1.0 / sqrt(fma(t, t, 1.0));
+    const double s = c * t;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const double gp = G[9 * i + P], gq = G[9 * i + Q];
+        G[9 * i + P] = fma(c, gp, -(s * gq));
+        G[9 * i + Q] = fma(s, gp, c * gq);
+    }
+    return rot;
+}
+
+// The careful path: what apap.py:159-161 computes, without squaring the condition number.
+//   1. the weighted rows w_k * aa[2k], w_k * aa[2k+1] (float64 weight times float32 entry, one
+//      rounding, like np.repeat(weight, 2)[:, None] * aa) are inserted one by one into a 9x9
+//      upper-triangular R by Givens rotations (row-wise backward stable for any weight grading);
+//      the float32 DLT entries are read back from the table, where they are stored exactly as
+//      products with the row's constant 1;
+//   2. one-sided Jacobi on the columns of G = R^T: G W has orthogonal columns sigma_j v_j, the right
+//      singular vectors of W A - no accumulation of rotations is needed;
+//   3. the column of the (pick_rank)-th smallest norm, normalised: the last row of the thin V^T.
+// Lanes = cells; the wave walks all n keypoints (their table rows are wave-uniform scalar loads).
+// Measured against a 60-digit SVD on the soak's ill-conditioned cells this is exact after the
+// float32 rounding, and within 3e-5 px of numpy's float64 SVD (whose own error that is).
+constexpr int kMaxHestenesSweeps = 30;
+
+__device__ __forceinline__ void qr_resolve(const double *__restrict__ table, int n, double vx, double vy,
+                                        double inv_sigma, double gamma, int pick_rank, double (&h)[9]) {
+    double R[45];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) R[k] = 0.0;
+    for (int p = 0; p < n; ++p) {
+        const double *__restrict__ row = table + (size_t)p * APAP_TABLE_STRIDE;
+        const double w = cell_weight(vx, vy, row[30], row[31], inv_sigma, gamma);
+        const double x = row[2], y = row[4];
+        double r[9];
+        r[0] = w * x; r[1] = w * y; r[2] = w; r[3] = 0.0; r[4] = 0.0; r[5] = 0.0;
+        r[6] = w * row[12]; r[7] = w * row[13]; r[8] = w * row[14];
+        givens_insert<0>(R, r); givens_insert<1>(R, r); givens_insert<2>(R, r);
+        givens_insert<3>(R, r); givens_insert<4>(R, r); givens_insert<5>(R, r);
+        givens_insert<6>(R, r); givens_insert<7>(R, r); givens_insert<8>(R, r);
+        r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = w * x; r[4] = w * y; r[5] = w;
+        r[6] = w * row[21]; r[7] = w * row[22]; r[8] = w * row[23];
+        givens_insert<3>(R, r); givens_insert<4>(R, r); givens_insert<5>(R, r);
+        givens_insert<6>(R, r); givens_insert<7>(R, r); givens_insert<8>(R, r);
+    }
+    // G = R^T scaled by a power of two so that squared column norms stay in range
+    double big = 0.0;
+#pragma unroll
+    for (int k = 0; k < 45; ++k) big = fmax(big, fabs(R[k]));
+    const int e = (big > 0.0 && big < 1.797e308) ? __builtin_amdgcn_frexp_exp(big) : 0;
+    double G[81];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) G[9 * i + j] = (j <= i) ? __builtin_ldexp(R[tri(j, i)], -e) : 0.0;
+    for (int sweep = 0; sweep < kMaxHestenesSweeps; ++sweep) {
+        bool any = false;
+#define APAP_PAIR(p, q) any |= hestenes_rotate<p, q>(G, 1e-15);
+        APAP_PAIR(0, 1) APAP_PAIR(0, 2) APAP_PAIR(0, 3) APAP_PAIR(0, 4) APAP_PAIR(0, 5) APAP_PAIR(0, 6) APAP_PAIR(0, 7) APAP_PAIR(0, 8)
+        APAP_PAIR(1, 2) APAP_PAIR(1, 3) APAP_PAIR(1, 4) APAP_PAIR(1, 5) APAP_PAIR(1, 6) APAP_PAIR(1, 7) APAP_PAIR(1, 8)
+        APAP_PAIR(2, 3) APAP_PAIR(2, 4) APAP_PAIR(2, 5) APAP_PAIR(2, 6) APAP_PAIR(2, 7) APAP_PAIR(2, 8)
+        APAP_PAIR(3, 4) APAP_PAIR(3, 5) APAP_PAIR(3, 6) APAP_PAIR(3, 7) APAP_PAIR(3, 8)
+        APAP_PAIR(4, 5) APAP_PAIR(4, 6) APAP_PAIR(4, 7) APAP_PAIR(4, 8)
+        APAP_PAIR(5, 6) APAP_PAIR(5, 7) APAP_PAIR(5, 8)
+        APAP_PAIR(6, 7) APAP_PAIR(6, 8)
+        APAP_PAIR(7, 8)
+#undef APAP_PAIR
+        if (!__any(any)) break;
+    }
+    double nrm2[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) acc = fma(G[9 * i + j], G[9 * i + j], acc);
+        nrm2[j] = acc;
+    }
+    // singular values sorted descending, equal ones in index order (a zero matrix gives V = I):
+    // rank = number of columns that sort AFTER this one
+    int best = 8;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j != i) rank += (nrm2[j] < nrm2[i] || (nrm2[j] == nrm2[i] && j > i)) ? 1 : 0;
+        best = (rank == pick_rank) ? i : best;
+    }
+    double nb = nrm2[0];
+#pragma unroll
+    for (int c = 1; c < 9; ++c) nb = (best == c) ? nrm2[c] : nb;
+    const double inv = nb > 0.0 ? 1.0 / sqrt(nb) : 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double x = G[9 * k];
+#pragma unroll
+        for (int c = 1; c < 9; ++c) x = (best == c) ? G[9 * k + c] : x;
+        h[k] = nb > 0.0 ? x * inv : (k == best ? 1.0 : 0.0);
+    }
 }
 
 // K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
@@ -664,10 +860,15 @@ template <bool kUseInverseIteration>
 __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
                                                      int cells, int cells_pad,
                                                      const double *__restrict__ denorm, int pick_rank,
-                                                     float *__restrict__ H, BatchStride bs) {
+                                                     float *__restrict__ H, BatchStride bs,
+                                                     const double *__restrict__ table, int n,
+                                                     const double *__restrict__ vertices, double gamma,
+                                                     double inv_sigma, int careful) {
     moments += (long long)blockIdx.z * bs.moments;
     denorm += (long long)blockIdx.z * bs.denorm;
     H += (long long)blockIdx.z * bs.H;
+    table += (long long)blockIdx.z * bs.table;
+    vertices += (long long)blockIdx.z * bs.vertices;
     const int cell = blockIdx.x * kWave + threadIdx.x;
     const int cc = min(cell, cells - 1);
     double m[kMoments];
@@ -695,15 +896,32 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
         }
     a[tri(6, 6)] = m[24]; a[tri(6, 7)] = m[25]; a[tri(6, 8)] = m[26];
     a[tri(7, 7)] = m[27]; a[tri(7, 8)] = m[28]; a[tri(8, 8)] = m[29];
+    const double gap_tol = kGapTol * (2.0 * (m[0] + m[3] + m[5]) + m[24] + m[27] + m[29]);  // kGapTol * trace
 
     double h[9];
     bool have = false;
-    if (kUseInverseIteration && pick_rank == 0) have = inverse_iteration(a, h);
-    if (!__all(have)) {  // rare: no spectral gap, rank-deficient system, n < 5
+    // Fewer than 5 keypoints (pick_rank != 0): the reference's V[-1] is the singular vector of the
+    // smallest KEPT singular value of the thin SVD, lambda_(9-2n) of a matrix with 9 - 2n exact
+    // zeros below it: always the careful path.
+    bool careful_cell = careful && pick_rank != 0;
+    if (kUseInverseIteration && pick_rank == 0) {
+        double rho;
+        have = inverse_iteration(a, h, rho);
+        // a second eigenvalue within gap_tol of the smallest?  (rho >= lambda_9, so lambda_9 counts)
+        if (careful) careful_cell = have && count_eigs_below(m, rho + gap_tol) >= 2;
+    }
+    if (!__all(have || careful_cell)) {  // rare: no spectral gap, pivot not positive (n < 5 with careful == 0)
         double hj[9];
-        jacobi_eigvec(a, pick_rank, hj);
+        const double gap = jacobi_eigvec(a, pick_rank, hj);
+        if (careful && pick_rank == 0 && !have) careful_cell = !(gap >= gap_tol);  // also for NaN
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = have ? h[k] : hj[k];
+    }
+    if (__any(careful_cell)) {
+        double hq[9];
+        qr_resolve(table, n, vertices[2 * cc], vertices[2 * cc + 1], inv_sigma, gamma, pick_rank, hq);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) h[k] = careful_cell ? hq[k] : h[k];
     }
     double t1[9], t2[9];
     mul3(denorm, h, t1);        // inv(C2) . h
@@ -1296,6 +1514,7 @@ using apap::ProfScope;
 
 int g_variant = APAP_VARIANT_AUTO;
 int g_eigen = APAP_EIGEN_AUTO;
+int g_careful = 1;
 
 // ---- optional per-kernel timing with HIP events on the launch stream ----
 struct ProfSpan {
@@ -1415,15 +1634,16 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
                                d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
     }
     const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
+    const int careful = g_careful;
     {
         ProfScope prof(APAP_PROF_EIGEN, s);
         const dim3 grid(p.cell_tiles, 1, batch);
         if (g_eigen == APAP_EIGEN_JACOBI)
             hipLaunchKernelGGL(k_eigen_denorm<false>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
-                               pick_rank, d_H, bs);
+                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful);
         else
             hipLaunchKernelGGL(k_eigen_denorm<true>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
-                               pick_rank, d_H, bs);
+                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");

@@ -17,8 +17,11 @@ script is how they were made.
     edge        edge_ref (10 corners of the parameter space), warp_edge_ref (5 corners of the warp geometry)
     prepare     prepare_ref (set-up at n = 8192 ... 50000), n20001_ref (a 6 x 6 grid from 20001 keypoints)
     C1 C2 C3    full H grids + the warped canvas (SHA-256 and sampled rows) of the BASELINE.json configs
-    C4          every 8th mesh row of the 400 x 400 grid (~7 minutes of the reference's loop)
-    C5          two of the 64 independent pairs
+    C4          every 8th mesh row of the 400 x 400 grid (~7 minutes of the reference's loop), SHA-256 of the
+                whole grid and of its in-place inverses, the 8K warped canvas (SHA-256 + every 256th row; ~3 min more)
+    C5          eight of the 64 independent pairs (pairs 0, 1 in full, 2..7 every 4th mesh row + SHA-256 of the grid)
+    illcond     illcond_ref: the six soak seeds of round 1 whose weighted systems are numerically rank-deficient
+                (gamma = 0, sigma <= 10 px, 5-17 keypoints), through the reference's APAP.local_homography
 
 Two things the reference needs that this image lacks, and how they are served:
 * ``cv2`` (OpenCV) is not installed.  ``apap.py`` uses exactly one OpenCV function on
@@ -126,6 +129,31 @@ def tiny_case(ref_apap, ref_utils, sigma, seed, name):
     print(f"{name}: canvas {fw}x{fh} offsets ({ox},{oy}) clamped fraction {clamped:.3f}")
 
 
+ILLCOND_SEEDS = (108, 544, 659, 795, 814, 883)   # tools/long_fuzz.py seeds (random_case(1000 + seed)), round 1
+
+
+def illcond_cases(ref_apap, name="illcond_ref.npz"):
+    """Inputs whose weighted DLT system is numerically rank-deficient (sigma_8 / sigma_1 down to 1e-11):
+    the solve must work on the weighted rows, not on A^T W^2 A.  Inputs are regenerated by the test
+    from the seed; only the reference's H grids are stored."""
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_fuzz import random_case
+    out = {"seeds": np.array(ILLCOND_SEEDS)}
+    for seed in ILLCOND_SEEDS:
+        c = random_case(1000 + seed)
+        fw, fh = c["canvas"]
+        eng = ref_apap.APAP(c["gamma"], c["sigma"], [fw, fh], list(c["off"]))
+        with np.errstate(all="ignore"):
+            H, _ = eng.local_homography(c["src"], c["dst"], c["verts"])
+        out[f"H{seed}"] = H
+        out[f"par{seed}"] = np.array([c["gamma"], c["sigma"], c["n"], H.shape[0], H.shape[1]])
+        out[f"src_sha{seed}"] = np.frombuffer(hashlib.sha256(c["src"].tobytes() + c["dst"].tobytes()
+                                                             + c["verts"].tobytes()).digest(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: seeds {ILLCOND_SEEDS}")
+
+
 def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_every=1, seed_offset=0):
     """A BASELINE.json config: full H grid from the reference; for the warp, a SHA-256 of
     the full canvas plus every ``warp_rows_every``-th row."""
@@ -139,7 +167,8 @@ def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_ev
     assert np.array_equal(ref_utils.get_vertice((fw, fh), m, (ox, oy)), p.vertices)
     eng = ref_apap.APAP(p.gamma, p.sigma, [fw, fh], [ox, oy])
     H_ref, W_ref = eng.local_homography(p.src, p.dst, p.vertices)
-    out = dict(H_ref=H_ref[::keep_rows_every].copy(), keep_rows_every=keep_rows_every,
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)  # noqa: E731
+    out = dict(H_ref=H_ref[::keep_rows_every].copy(), keep_rows_every=keep_rows_every, H_sha256=sha(H_ref),
                final=np.array([fw, fh, ox, oy], dtype=np.int64),
                W_checksum=np.array([W_ref.sum(), (W_ref * W_ref).sum()]),
                W_row0=W_ref[0, 0].copy(), W_last=W_ref[-1, -1].copy())
@@ -147,7 +176,8 @@ def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_ev
     if warp_rows_every:
         H_arg = H_ref.copy()
         warped = eng.local_warp(p.img, H_arg, p.mesh, False)
-        out.update(Hinv_ref=H_arg, warped_rows=warped[::warp_rows_every].copy(),
+        out.update(Hinv_ref=H_arg[::keep_rows_every].copy(), Hinv_sha256=sha(H_arg),
+                   warped_rows=warped[::warp_rows_every].copy(),
                    warp_rows_every=warp_rows_every,
                    warped_sha256=np.frombuffer(hashlib.sha256(warped.tobytes()).digest(), dtype=np.uint8))
     np.savez_compressed(os.path.join(HERE, name), **out)
@@ -313,11 +343,14 @@ def main():
         config_case(ref_apap, ref_utils, "C3", "c3_ref.npz", warp_rows_every=64)
     if "C5" in which:
         # two of the 64 independent pairs of C5 (seed 6400 + k), ~12 s each in the reference's loop
-        for k in (0, 1):
-            config_case(ref_apap, ref_utils, "C5", f"c5_ref_k{k}.npz", warp_rows_every=0, seed_offset=k)
+        for k in range(8):
+            config_case(ref_apap, ref_utils, "C5", f"c5_ref_k{k}.npz", warp_rows_every=0, seed_offset=k,
+                        keep_rows_every=1 if k < 2 else 4)
     if "C4" in which:
         # ~7 minutes in the reference's Python loop; only every 8th mesh row is kept (720 KB)
-        config_case(ref_apap, ref_utils, "C4", "c4_ref_rows8.npz", warp_rows_every=0, keep_rows_every=8)
+        config_case(ref_apap, ref_utils, "C4", "c4_ref_rows8.npz", warp_rows_every=256, keep_rows_every=8)
+    if "illcond" in which:
+        illcond_cases(ref_apap)
 
 
 if __name__ == "__main__":
