@@ -187,7 +187,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma", "mfma4", "mfma4x2"])
     ap.add_argument("--mode", default="pairs", choices=["pairs", "cells"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=1,
@@ -222,7 +222,7 @@ def main():
     else:
         dist = None
 
-    N.lib().apap_set_solver_variant({"auto": 0, "valu": 1, "mfma": 2}[a.variant])
+    N.lib().apap_set_solver_variant({"auto": 0, "valu": 1, "mfma": 2, "mfma4": 3, "mfma4x2": 4}[a.variant])
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():

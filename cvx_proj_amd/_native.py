@@ -22,7 +22,7 @@ PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply
 PROF_SLOTS = len(PROF_NAMES)
 TABLE_STRIDE = 32
 DENORM_DOUBLES = 36
-VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA = 0, 1, 2
+VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1, 2, 3, 4
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 
 

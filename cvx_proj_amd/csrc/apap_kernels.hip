@@ -464,6 +464,124 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
 }
 
 // --------------------------------------------------------------------------------
+// K1 (small-MFMA variant): the same lane -> (cell, keypoint) mapping, accumulated by
+// v_mfma_f64_4x4x4_4b_f64 (4 blocks of 4x4x4: block b = cells 4b..4b+3 of a 16-cell group, j = 4
+// table columns).  Operand layout (tools/mfma4_layout.hip): A[b][i][k] in lane 16k + 4b + i,
+// B[b][k][j] in lane 16k + 4b + j, D[b][i][j] in lane 16i + 4b + j.  Eight instructions cover the
+// 32 table columns; a wave owns kGroups 16-cell groups that share every B operand.
+// Why it exists: tools/coexec.hip shows that NO vector instruction co-executes with an f64 MFMA on
+// this chip - issue time simply adds up - and that in a pure stream the 16x16x4 form costs ~104
+// cycles per instruction where four 4x4x4_4b cost 4 x 16.3 (profiles/r02_coexec.txt).  Measured in
+// the kernel (profiles/r02_k1_variants.txt): C3 178-182 us with 16 cells per wave, 163-168 us with
+// 32 (one more slab for K2), against 167-170 us for the 16x16x4 kernel and 172-174 us for the VALU
+// kernel: every form ends at ~266 issue cycles per 64 (cell, keypoint) pairs = 128 for the
+// accumulation (32 x 4) + the weight chain.  The fp64 pipe is the bound, not the MFMA shape.
+// --------------------------------------------------------------------------------
+template <int kGroups>
+__global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict__ table, int n,
+                                                        const double *__restrict__ vertices, int cells,
+                                                        int cells_pad, double gamma2, double inv_sigma2,
+                                                        int pts_per_split, double *__restrict__ moments,
+                                                        BatchStride bs) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
+    table += (long long)blockIdx.z * bs.table;
+    vertices += (long long)blockIdx.z * bs.vertices;
+    moments += (long long)blockIdx.z * bs.moments;
+    __shared__ double s_exp2[kExpN];
+    for (int j = threadIdx.x; j < kExpN; j += 256) s_exp2[j] = kExp2Tab[j];  // visible after the first barrier
+    const double scaled_inv_sigma2 = inv_sigma2 * kExpScale;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int kgrp = lane >> 4;  // which of the step's 4 keypoints this lane weighs / reads B for
+    const int col = lane & 15;   // cell within a 16-cell group (A operand)
+    const int cell0 = (blockIdx.x * 4 + wave) * (16 * kGroups);
+    double vx[kGroups], vy[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const int cc = min(cell0 + 16 * g + col, cells - 1);
+        vx[g] = vertices[2 * cc];
+        vy[g] = vertices[2 * cc + 1];
+    }
+    const int p_begin = min(n, (int)blockIdx.y * pts_per_split);
+    const int p_end = min(n, p_begin + pts_per_split);
+    const int nchunks = (p_end - p_begin + kChunk - 1) / kChunk;
+
+    constexpr int kPieces = kChunk * 16 / 256;  // 16-byte pieces of a chunk per thread
+    double2 stage[kPieces];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = tid + 256 * i;
+            const int p = p_begin + c * kChunk + (q >> 4);
+            stage[i] = (p < p_end) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
+                                   : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_chunk = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = tid + 256 * i;
+            const int r = q >> 4;
+            const int slot = (q & 15) ^ ((r & 1) << 3);
+            *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[i];
+        }
+    };
+
+    const int off_xy = lds_off(kgrp, 30);
+    // column 4 m + j of row kgrp: the swizzle only flips bit 4 of the column, so two per-lane bases
+    // (columns 0-15 and 16-31) plus the immediate 32 (m & 3)
+    const int off_lo = lds_off(kgrp, lane & 3), off_hi = lds_off(kgrp, 16 + (lane & 3));
+    double acc[kGroups][8];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[g][m] = 0.0;
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): see k_assemble_mfma
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const unsigned char *buf = lds[c & 1];
+#pragma unroll
+        for (int s = 0; s < kChunk / 4; ++s) {
+            const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * s);
+            double bv[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                bv[m] = *reinterpret_cast<const double *>(buf + (m < 4 ? off_lo : off_hi) + 32 * (m & 3) + 1024 * s);
+            double w2[kGroups];
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g)
+                w2[g] = cell_weight_sq_tab(vx[g], vy[g], xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int g = 0; g < kGroups; ++g)
+                    acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(w2[g], bv[m], acc[g][m], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+    // D[b][i][j] sits in lane 16 i + 4 b + j: cell 4 b + i of the group, table column 4 m + j
+    double *slab = moments + (size_t)blockIdx.y * kMoments * cells_pad;
+    const int dcell = 4 * ((lane >> 2) & 3) + (lane >> 4);
+    const int dj = lane & 3;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const int ci = cell0 + 16 * g + dcell;
+        if (ci < cells_pad) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (4 * m + dj < kMoments) slab[(size_t)(4 * m + dj) * cells_pad + ci] = acc[g][m];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------
 // K2: per-cell symmetric 9x9 eigen-solve, lanes = cells, everything in registers: inverse
 // iteration on an L D L^T factorisation by default, cyclic Jacobi sweeps (45 + 81 doubles)
 // as the fallback and as the selectable alternative; then the eigenvector of the smallest
@@ -1565,10 +1683,11 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch) {
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 4096;
     }();
-    // waves per (64-cell tile, split): the MFMA kernel's block is 4 waves on one tile, the VALU
-    // kernel's is 4 waves on 4 tiles
-    const int waves_per_tile = variant == APAP_VARIANT_MFMA ? 4 : 1;
-    while (splits < 32 && (long long)p.cell_tiles * batch * waves_per_tile * splits < want_waves && n / (splits * 2) >= kChunk) splits *= 2;
+    // waves per (64-cell tile, split): the MFMA kernels' block is 4 waves on one tile (two tiles for
+    // APAP_VARIANT_MFMA4X2), the VALU kernel's is 4 waves on 4 tiles
+    const int waves_per_2tiles = variant == APAP_VARIANT_MFMA || variant == APAP_VARIANT_MFMA4 ? 8
+                                 : variant == APAP_VARIANT_MFMA4X2 ? 4 : 2;
+    while (splits < 32 && (long long)p.cell_tiles * batch * waves_per_2tiles * splits < 2 * want_waves && n / (splits * 2) >= kChunk) splits *= 2;
     int pps = (n + splits - 1) / splits;
     pps = (pps + kChunk - 1) / kChunk * kChunk;
     p.splits = (n + pps - 1) / pps;  // no empty split
@@ -1583,7 +1702,7 @@ extern "C" {
 
 int apap_set_solver_variant(int variant) {
     const int prev = g_variant;
-    if (variant == APAP_VARIANT_AUTO || variant == APAP_VARIANT_VALU || variant == APAP_VARIANT_MFMA) g_variant = variant;
+    if (variant >= APAP_VARIANT_AUTO && variant <= APAP_VARIANT_MFMA4X2) g_variant = variant;
     return prev;
 }
 
@@ -1629,6 +1748,12 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
         if (p.variant == APAP_VARIANT_MFMA)
             hipLaunchKernelGGL(k_assemble_mfma<4>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
                                inv_sigma2, p.pts_per_split, moments, bs);
+        else if (p.variant == APAP_VARIANT_MFMA4)
+            hipLaunchKernelGGL(k_assemble_mfma4<1>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
+                               inv_sigma2, p.pts_per_split, moments, bs);
+        else if (p.variant == APAP_VARIANT_MFMA4X2)
+            hipLaunchKernelGGL(k_assemble_mfma4<2>, dim3((p.cell_tiles + 1) / 2, p.splits, batch), dim3(256), 0, s, d_tables, n,
+                               d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
         else
             hipLaunchKernelGGL(k_assemble_valu, dim3((p.cell_tiles + 3) / 4, p.splits, batch), dim3(256), 0, s, d_tables, n,
                                d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);

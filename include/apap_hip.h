@@ -55,6 +55,8 @@ extern "C" {
 #define APAP_VARIANT_AUTO 0
 #define APAP_VARIANT_VALU 1 /* one lane per cell, fp64 FMA accumulation            */
 #define APAP_VARIANT_MFMA 2 /* v_mfma_f64_16x16x4_f64 accumulation, table via LDS  */
+#define APAP_VARIANT_MFMA4 3   /* v_mfma_f64_4x4x4_4b_f64, 16 cells per wave          */
+#define APAP_VARIANT_MFMA4X2 4 /* v_mfma_f64_4x4x4_4b_f64, 32 cells per wave share B  */
 
 /* Eigen-solvers of K2 (apap_set_eigen_solver). */
 #define APAP_EIGEN_AUTO 0              /* = inverse iteration with Jacobi fallback          */

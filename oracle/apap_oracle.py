@@ -359,22 +359,23 @@ def warp_coords_fast(hinv, mesh, final_wh, offset):
         return t0 / t2, t1 / t2
 
 
-def local_warp_fast(ori_img, hinv, mesh, final_wh, offset, band=256):
+def local_warp_fast(ori_img, hinv, mesh, final_wh, offset, band=256, rows=None):
     """Vectorised restatement of the pixel loop given ALREADY INVERTED cells.  Strict
     ``0 < t < size`` test and truncation as apap.py:214-215.  Works in row bands to
-    bound memory."""
+    bound memory.  ``rows`` restricts the output to those canvas rows (returned stacked)."""
     final_w, final_h = final_wh
     ori_h, ori_w, _ = ori_img.shape
     mesh_w, mesh_h = mesh
     off_x, off_y = offset
     rc_all = cell_lookup(final_h, mesh_h)
     cc = cell_lookup(final_w, mesh_w)
-    warped = np.zeros((final_h, final_w, 3), dtype=np.uint8)
+    row_ids = np.arange(final_h) if rows is None else np.asarray(rows, dtype=np.int64)
+    warped = np.zeros((len(row_ids), final_w, 3), dtype=np.uint8)
     x = (np.arange(final_w) - off_x).astype(np.float64)[None, :]
-    for lo in range(0, final_h, band):
-        hi = min(final_h, lo + band)
-        hc = hinv[rc_all[lo:hi]][:, cc].astype(np.float64)
-        y = (np.arange(lo, hi) - off_y).astype(np.float64)[:, None]
+    for lo in range(0, len(row_ids), band):
+        hi = min(len(row_ids), lo + band)
+        hc = hinv[rc_all[row_ids[lo:hi]]][:, cc].astype(np.float64)
+        y = (row_ids[lo:hi] - off_y).astype(np.float64)[:, None]
         t0 = hc[..., 0, 0] * x + hc[..., 0, 1] * y + hc[..., 0, 2]
         t1 = hc[..., 1, 0] * x + hc[..., 1, 1] * y + hc[..., 1, 2]
         t2 = hc[..., 2, 0] * x + hc[..., 2, 1] * y + hc[..., 2, 2]

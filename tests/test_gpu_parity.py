@@ -26,10 +26,11 @@ def need_gpu(native):
     assert native.lib().apap_device_count() >= 1, "these tests need a GPU; the library found none"
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (2, 1), (2, 2)], ids=["valu-jacobi", "valu-invit", "mfma-jacobi", "mfma-invit"])
+@pytest.fixture(params=[(1, 1), (1, 2), (2, 1), (2, 2), (3, 2), (4, 2)],
+                ids=["valu-jacobi", "valu-invit", "mfma-jacobi", "mfma-invit", "mfma4-invit", "mfma4x2-invit"])
 def variant(request, native):
-    """All combinations of the K1 kernel (VALU / MFMA) and the K2 eigen-solver
-    (Jacobi / inverse iteration with Jacobi fallback)."""
+    """Combinations of the K1 kernel (VALU / MFMA 16x16x4 / MFMA 4x4x4 with 16 or 32 cells per wave)
+    and the K2 eigen-solver (Jacobi / inverse iteration with Jacobi fallback)."""
     prev = native.lib().apap_set_solver_variant(request.param[0])
     prev_e = native.lib().apap_set_eigen_solver(request.param[1])
     yield request.param
@@ -358,21 +359,64 @@ def test_c4_full_size_solve_vs_oracle_subset(native, golden):
     assert jump.max() < 50 * np.median(jump) + 1e-6
 
 
+def test_c4_whole_path_vs_reference(native, golden):
+    """Config C4 end to end against the REFERENCE (tests/golden/c4_ref_rows8.npz: ~10 minutes of its
+    loops): the whole 400 x 400 grid bit for bit (SHA-256 of the reference's float32 array), then
+    local_warp (apap.py:186-217) of the 7680 x 4320 image onto the 8018 x 4485 canvas - SHA-256 of
+    the canvas and of the in-place inverses, every 256th canvas row - and the same canvas from
+    apap_warp_rows_device over uneven row bands (what the ranks of ShardedSolver.warp compute)."""
+    import hashlib
+    import torch
+    from cvx_proj_amd.dist import ShardedSolver, hip_warp_rows
+    g = golden("c4_ref_rows8")
+    p = config_pair("C4")
+    assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
+    H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    assert hashlib.sha256(H.tobytes()).digest() == g["H_sha256"].tobytes(), "C4 grid differs from the reference's"
+    Harg = H.copy()
+    eng = APAP(p.gamma, p.sigma, [p.final_w, p.final_h], [p.off_x, p.off_y])
+    warped = eng.local_warp(p.img, Harg, p.mesh)
+    every = int(g["warp_rows_every"])
+    assert np.array_equal(warped[::every], g["warped_rows"])
+    assert hashlib.sha256(warped.tobytes()).digest() == g["warped_sha256"].tobytes()
+    assert hashlib.sha256(Harg.tobytes()).digest() == g["Hinv_sha256"].tobytes()      # the mutated argument
+    assert np.array_equal(Harg[::int(g["keep_rows_every"])], g["Hinv_ref"])
+    # sharded: the bands of 3 and of 8 ranks, plus deliberately uneven ones, reassemble the same canvas
+    s = ShardedSolver(p, torch.device("cuda:0"), None)
+    s.H.copy_(torch.from_numpy(H.reshape(-1, 9)))
+    full = s.warp()
+    assert np.array_equal(full.cpu().numpy(), warped)
+    from cvx_proj_amd.dist import row_partition
+    for bands in (row_partition(p.final_h, 3), row_partition(p.final_h, 8),
+                  [(0, 1), (1, 1000), (1000, 1003), (1003, 4000), (4000, p.final_h)]):
+        out = torch.zeros_like(s.out)
+        for a, b in bands:
+            band = torch.zeros((b - a, p.final_w, 3), dtype=torch.uint8, device=out.device)
+            st = hip_warp_rows(s.img, s.H, s.mesh_w, s.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a, band,
+                               (400, 400))
+            assert int(st.cpu()[0]) == 0
+            out[a:b] = band
+        assert torch.equal(out, full)
+
+
 def test_c5_pairs_through_driver(native, golden):
     """Batch of independent 4K pairs (config C5) through cvx_proj_amd.dist.solve_pairs on one
-    rank; pairs 0 and 1 against the reference's own grids, all four against the oracle."""
+    rank: eight of the 64 pairs against the reference's own grids (pairs 0, 1 element by element,
+    2..7 by the SHA-256 of the whole grid + every 4th mesh row), all against the oracle."""
+    import hashlib
     import torch
     from cvx_proj_amd.dist import solve_pairs
-    pairs = [config_pair("C5", with_image=False, seed_offset=k) for k in range(4)]
+    pairs = [config_pair("C5", with_image=False, seed_offset=k) for k in range(8)]
     grids = solve_pairs(pairs, torch.device("cuda:0"))
-    assert len(grids) == 4
+    assert len(grids) == 8
     for k, (g, p) in enumerate(zip(grids, pairs)):
         H_ref, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
         assert report(f"C5 pair {k}", g, H_ref, p.src[:128]).max() < RMSE_BAR
-        if k < 2:
-            ref = golden(f"c5_ref_k{k}")["H_ref"]
-            assert report(f"C5 pair {k} vs reference", g, ref, p.src[:128]).max() < RMSE_BAR
-            assert np.array_equal(g, ref)
+        gold = golden(f"c5_ref_k{k}")
+        every = int(gold["keep_rows_every"])
+        assert report(f"C5 pair {k} vs reference", g[::every], gold["H_ref"], p.src[:128]).max() < RMSE_BAR
+        assert np.array_equal(g[::every], gold["H_ref"])
+        assert hashlib.sha256(g.tobytes()).digest() == gold["H_sha256"].tobytes()
     assert not np.array_equal(grids[0], grids[1])
 
 

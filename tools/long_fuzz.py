@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off soak: the seeded differential fuzz tests of tests/test_gpu_fuzz.py over many more
-seeds than the test suite runs.  Prints the seeds that fail.   python tools/long_fuzz.py 40 400"""
+seeds than the test suite runs.  Prints the seeds that fail.
+    python tools/long_fuzz.py 40 400 [test_fuzz_solve_and_warp ...]"""
 import os
 import sys
 import traceback
@@ -20,7 +21,7 @@ def main():
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
     _native.lib()
     bad = []
-    for name in ("test_fuzz_solve_and_warp", "test_fuzz_equalize", "test_fuzz_ransac"):
+    for name in (sys.argv[3:] or ("test_fuzz_solve_and_warp", "test_fuzz_equalize", "test_fuzz_ransac")):
         fn = getattr(T, name)
         for seed in range(lo, hi):
             try:
