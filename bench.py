@@ -2,35 +2,44 @@
 """Benchmark of the APAP hot path on MI355X: local homographies/s and warp Mpix/s on the
 4K pair / 200x200 mesh / 2000 keypoints configuration of BASELINE.json (C3).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--variant auto|valu|mfma]
-                    [--no-cpu-baseline] [--mode pairs|cells]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3] [--cells-config C4]
+                    [--variant auto|valu|mfma|mfma4|mfma4x2] [--no-cpu-baseline] [--no-cells] [--no-call-level]
 
 A "step" is one pass of the hot path over one image pair with all inputs resident in
 HBM: the per-cell solve (assemble + eigen-solve kernels) and the backward warp
-(invert + lookup + gather kernels).  The two halves of the metric are timed in two
-regions of exactly K steps each, both bracketed by a barrier and a device synchronise:
+(set-up + gather kernels).  The two halves of the metric are timed in two regions of
+exactly K steps each, both bracketed by a barrier and a device synchronise:
 ``value`` = cells * K * N / t_solve (homographies/s), ``warp.value`` = canvas pixels
 * K * N / t_warp (Mpix/s), ``ms_per_step`` = (t_solve + t_warp) / K.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): ``--mode pairs``
-(default) gives every rank its own 4K pair - pairs are independent, no collective on
-the data path, weak scaling.  ``--mode cells`` shards the mesh rows of ONE pair over
-the ranks with a broadcast of the keypoint table and an all-gather of the H grid
-(cvx_proj_amd.dist), strong scaling.
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+``python -m torch.distributed.run --nproc-per-node N bench.py ...`` before anything touches the
+GPU); under torch.distributed.run it is one rank per GPU over RCCL.  Every run measures BOTH ways
+the path shards and puts both in the one JSON line:
 
-Extra objects on the JSON line: ``roofline`` for the dominant kernel (K1, timed live
-with HIP events on the launch stream) and ``cpu_baseline`` (the oracle's
-faithful-loop numpy port timed on this host, one thread, bounded sample).
+* ``pairs`` = the headline (``value``): every rank owns a 4K pair (config C3) - independent
+  units, no data-path collective, weak scaling;
+* ``cells`` = ONE pair of ``--cells-config`` (C4: 8K, 5000 keypoints, 400 x 400 mesh) with its mesh
+  rows sharded over the ranks by cvx_proj_amd.dist.ShardedSolver: table broadcast from rank 0 once
+  per pair, per-rank solve, all-gather of the H grid; warp by canvas-row bands + all-gather - strong
+  scaling.  At N = 1 it is the single-GPU baseline of that curve.
+
+Further objects: ``roofline`` for the dominant kernel (K1, timed live with HIP events on the launch
+stream), ``call_level`` (numpy in -> numpy out through the host-buffer entry points: host set-up,
+PCIe and synchronisation included) and ``cpu_baseline`` (the oracle's faithful-loop numpy port on
+this host: 1 thread, default BLAS threads, all usable cores).
 """
 import os
 
-os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # the CPU baseline is the 1-thread port
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")   # the CPU baseline's first row is the 1-thread port
 os.environ.setdefault("OMP_NUM_THREADS", "1")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import argparse
 import ctypes
 import json
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,6 +60,7 @@ PEAK_FP64_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 # algorithmic flops per (cell, keypoint) of K1, SURVEY.md 8(d): 8 (weight) + 48 (24 FMAs) + 2
 K1_FLOPS_PER_CELL_POINT = 58.0
+VARIANTS = {"auto": 0, "valu": 1, "mfma": 2, "mfma4": 3, "mfma4x2": 4}
 
 
 class Resident:
@@ -143,9 +153,58 @@ class Resident:
                                            self.status.data_ptr(), ctypes.c_void_p(stream)))
 
 
-def cpu_baseline(cfg, budget_cells, budget_rows, pool_workers=0):
-    """The oracle's faithful-loop port on this host: a bounded, seeded sample of the
-    same workload (cells spread over the mesh; every k-th canvas row)."""
+# ------------------------------------------------------------------------------------ CPU baseline
+_DEFAULT_THREADS_SNIPPET = r"""
+import json, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import apap_oracle as O
+from cvx_proj_amd.synth import config_pair
+p = config_pair({cfg!r}, with_image=False)
+rows, cols = p.vertices.shape[:2]
+flat = np.random.default_rng(0).choice(rows * cols, size=min({cells}, rows * cols), replace=False)
+done, t0 = 0, time.perf_counter()
+for f in flat:
+    O.local_homography_loop(p.src, p.dst, p.vertices, p.gamma, p.sigma, cells=[(int(f // cols), int(f % cols))], want_weights=True)
+    done += 1
+    if time.perf_counter() - t0 > {budget}:
+        break
+try:
+    from threadpoolctl import threadpool_info
+    threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+except Exception:
+    threads = None
+print(json.dumps({{"cells": done, "seconds": time.perf_counter() - t0, "blas_threads": threads}}))
+"""
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask, cut by the cgroup CPU quota when there
+    is one (a container on a 256-thread host is often allowed a fraction of it)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]           # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(cfg, budget_cells, budget_rows, pool_workers, default_threads_budget_s=8.0):
+    """The oracle's faithful-loop port on this host: a bounded, seeded sample of the same workload
+    (cells spread over the mesh; every k-th canvas row).  Three rows, SURVEY.md 8(d): one thread (the
+    headline of this object), default BLAS threading (a subprocess without the thread pins), all usable
+    cores (a process pool over the same cells, one BLAS thread each)."""
     from oracle import apap_oracle as O
     p = config_pair(cfg)
     rows, cols = p.vertices.shape[:2]
@@ -162,23 +221,108 @@ def cpu_baseline(cfg, budget_cells, budget_rows, pool_workers=0):
     O.local_warp_loop(p.img, hinv, p.mesh, (p.final_w, p.final_h), (p.off_x, p.off_y), rows_subset=sub)
     t_warp = time.perf_counter() - t0
     # the in-place inversion of all cells is part of local_warp; it is inside t_warp, as in the reference
+
+    default_threads = None
+    if default_threads_budget_s > 0:
+        env = {k: v for k, v in os.environ.items() if k not in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+        code = _DEFAULT_THREADS_SNIPPET.format(root=ROOT, cfg=cfg, cells=min(budget_cells, 4000), budget=default_threads_budget_s)
+        try:
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                               timeout=default_threads_budget_s * 6 + 120)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            default_threads = {"value": d["cells"] / d["seconds"], "unit": "homographies/s", "cores": d["blas_threads"],
+                               "kind": "port",
+                               "sample": f"{d['cells']} seeded cells in {d['seconds']:.1f} s, the same loop in a subprocess "
+                                         f"with no OPENBLAS/OMP thread limit (what a user of the reference gets by default)"}
+        except Exception as e:      # noqa: BLE001  (a baseline row must not take the GPU numbers down with it)
+            default_threads = {"error": repr(e)[:200]}
+
     pool = None
     if pool_workers > 1:
-        # "best-effort CPU" row of BASELINE.md: the same loop over a process pool, 1 BLAS thread each
-        Hp, t_pool = O.local_homography_pool(p.src, p.dst, p.vertices, p.gamma, p.sigma, cells, pool_workers)
-        assert np.array_equal(Hp, H)
-        pool = {"value": len(cells) / t_pool, "unit": "homographies/s", "cores": pool_workers, "kind": "port",
-                "sample": f"same {len(cells)} cells over a {pool_workers}-process pool (1 BLAS thread each; worker "
-                          f"start-up excluded), {t_pool:.2f} s"}
+        # "best-effort CPU" row: the same loop over a process pool, 1 BLAS thread each
+        try:
+            Hp, t_pool = O.local_homography_pool(p.src, p.dst, p.vertices, p.gamma, p.sigma, cells, pool_workers)
+            assert np.array_equal(Hp, H)
+            pool = {"value": len(cells) / t_pool, "unit": "homographies/s", "cores": pool_workers, "kind": "port",
+                    "sample": f"same {len(cells)} cells over a {pool_workers}-process pool (1 BLAS thread each; worker "
+                              f"start-up excluded), {t_pool:.2f} s"}
+        except Exception as e:      # noqa: BLE001
+            pool = {"error": repr(e)[:200]}
     return {
-        "pool": pool,
         "value": len(cells) / t_solve, "unit": "homographies/s", "cores": 1, "kind": "port",
         "sample": f"{len(cells)} of {rows * cols} cells (seeded random), {len(sub)} of {p.final_h} canvas rows + all "
                   f"{rows * cols} cell inversions; oracle faithful-loop numpy port, OPENBLAS_NUM_THREADS=1, "
-                  f"host has {os.cpu_count()} logical cores",
+                  f"host has {os.cpu_count()} logical cores, {usable_cores()} usable by this process",
         "warp_value": len(sub) * p.final_w / t_warp / 1e6, "warp_unit": "Mpix/s",
         "solve_s": t_solve, "warp_s": t_warp,
+        "default_blas_threads": default_threads,
+        "all_cores": pool,
     }
+
+
+# --------------------------------------------------------------------------------------- call level
+def call_level(cfg, reps=7):
+    """numpy in -> numpy out through the host-buffer entry points (what a caller of the reference's
+    class sees): host set-up (a2-a5 + table), H2D, kernels, D2H and the synchronisation included."""
+    p = config_pair(cfg)
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    H, _ = N.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)     # warm-up: pool allocation
+    cells = H.shape[0] * H.shape[1]
+    t_h = med(lambda: N.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False), reps)
+    N.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    t_w = med(lambda: N.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y), max(reps - 2, 3))
+    t_hw = med(lambda: N.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=True), 3)
+    return {"workload": cfg, "local_homography_ms": t_h * 1e3, "homographies_per_s": cells / t_h,
+            "local_warp_ms": t_w * 1e3, "warp_mpix_per_s": p.final_w * p.final_h / t_w / 1e6,
+            "local_homography_with_weights_ms": t_hw * 1e3, "weights_bytes": cells * len(p.src) * 8,
+            "note": "median wall time of apap_local_homography / apap_local_warp called with host (numpy) buffers: "
+                    "host set-up, pageable-memory H2D/D2H over PCIe and the final synchronisation are inside; "
+                    "never `value`"}
+
+
+# ------------------------------------------------------------------------------------ self-launch
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(gpus):
+    """Start the ranks as a CHILD process tree (never exec: this parent has not touched the GPU and
+    must not be replaced once anything has) and return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def selftest(rank, world):
+    """APAP_BENCH_SELFTEST=1: exercise the launch + rendezvous + one collective without a GPU (the
+    CPU test of the self-launch path): every rank contributes rank + 1, rank 0 prints the sum."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "sum": float(t[0]),
+                          "ranks_env": [os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------- main
+def read_kernel_ms():
+    ms = (ctypes.c_float * N.PROF_SLOTS)()
+    cnt = (ctypes.c_int * N.PROF_SLOTS)()
+    N.check(N.lib().apap_profile_read(ms, cnt))
+    return {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(N.PROF_NAMES) if cnt[i] or i < 5}
 
 
 def main():
@@ -187,9 +331,12 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C3", choices=sorted(CONFIGS))
-    ap.add_argument("--variant", default="auto", choices=["auto", "valu", "mfma", "mfma4", "mfma4x2"])
-    ap.add_argument("--mode", default="pairs", choices=["pairs", "cells"])
+    ap.add_argument("--cells-config", default="C4", choices=sorted(CONFIGS),
+                    help="the ONE pair whose mesh rows are sharded over the ranks in the `cells` object")
+    ap.add_argument("--variant", default="auto", choices=sorted(VARIANTS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cells", action="store_true", help="skip the `cells` (strong-scaling) object")
+    ap.add_argument("--no-call-level", action="store_true")
     ap.add_argument("--batch", type=int, default=1,
                     help="solve this many independent pairs per step in ONE batched launch (config C5 style); "
                          "the warp half then runs once per pair")
@@ -197,21 +344,24 @@ def main():
                     help="capture the solve and the warp step into HIP graphs and time graph replays")
     ap.add_argument("--cpu-cells", type=int, default=40000)
     ap.add_argument("--cpu-rows", type=int, default=400)
-    ap.add_argument("--cpu-pool", type=int, default=16, help="workers of the process-pool CPU row (0 = skip)")
+    ap.add_argument("--cpu-pool", type=int, default=-1,
+                    help="workers of the all-cores CPU row (-1 = every core this process may use, 0 = skip)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a.gpus))       # nothing above this line touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
+    if os.environ.get("APAP_BENCH_SELFTEST") == "1":
+        return selftest(rank, world)
     # one rank per GPU; if a rehearsal runs more ranks than GPUs (e.g. 2 gloo ranks on a 1-GPU
     # box, APAP_BENCH_BACKEND=gloo) the ranks share devices round-robin
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("APAP_BENCH_BACKEND", "nccl")      # nccl = RCCL on ROCm
@@ -222,7 +372,7 @@ def main():
     else:
         dist = None
 
-    N.lib().apap_set_solver_variant({"auto": 0, "valu": 1, "mfma": 2, "mfma4": 3, "mfma4x2": 4}[a.variant])
+    N.lib().apap_set_solver_variant(VARIANTS[a.variant])
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -231,26 +381,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.mode == "cells" and world > 1:
-        from cvx_proj_amd.dist import ShardedSolver
-        pair = config_pair(a.config)
-        res = ShardedSolver(pair, dev, dist)
-        units_solve = res.cells_total                # strong scaling: one pair for the whole job
-        units_warp = pair.final_w * pair.final_h
-        scaling = "strong"
-    else:
-        pair = config_pair(a.config, seed_offset=rank * a.batch)
-        extras = [config_pair(a.config, with_image=False, seed_offset=rank * a.batch + k) for k in range(1, a.batch)]
-        res = Resident(pair, dev, a.batch, extras)
-        units_solve = res.cells * a.batch * world
-        units_warp = pair.final_w * pair.final_h * world
-        scaling = "weak"
+    def timed(fn, steps):
+        """EXACTLY `steps` calls between two barrier + synchronise brackets; max over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        barrier()
+        t = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([t], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.cpu()[0])
+        return t
+
+    # ------------------------------------------------------------------ pairs: the headline
+    pair = config_pair(a.config, seed_offset=rank * a.batch)
+    extras = [config_pair(a.config, with_image=False, seed_offset=rank * a.batch + k) for k in range(1, a.batch)]
+    res = Resident(pair, dev, a.batch, extras)
+    units_solve = res.cells * a.batch * world
+    units_warp = pair.final_w * pair.final_h * world
 
     for _ in range(a.warmup):
         res.solve(stream)
         res.warp(stream)
     run_solve, run_warp = (lambda: res.solve(stream)), (lambda: res.warp(stream))
-    if a.graph and isinstance(res, Resident):
+    if a.graph:
         # the entry points only enqueue kernels (no allocation, no synchronisation), so a step
         # can be captured once and replayed: one host call per step instead of one per kernel
         torch.cuda.synchronize()
@@ -262,77 +418,92 @@ def main():
         run_solve, run_warp = g_solve.replay, g_warp.replay
         run_solve()
         run_warp()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run_solve()
-    barrier()
-    t_solve = time.perf_counter() - t0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        run_warp()
-    barrier()
-    t_warp = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([t_solve, t_warp], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        t_solve, t_warp = (float(v) for v in tt.cpu())
+    t_solve = timed(run_solve, a.steps)
+    t_warp = timed(run_warp, a.steps)
     assert int(res.status.cpu()[0]) == 0, "device status word set during the timed region"
-    t_stitch = None
-    if hasattr(res, "stitch"):      # extra: the fused stitch, same canvas, not part of `value`
-        res.stitch(stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            res.stitch(stream)
-        torch.cuda.synchronize()
-        t_stitch = time.perf_counter() - t0
-        res.warp(stream)            # leave the plain warped canvas in res.out for the byte count below
-        torch.cuda.synchronize()
 
-    t_eq = None
-    if hasattr(res, "equalize"):    # extra: the pre-processing of both images is one call each
-        res.equalize(stream)
+    def extra(fn):      # rank-local extras, not part of `value`
+        fn(stream)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
-            res.equalize(stream)
+            fn(stream)
         torch.cuda.synchronize()
-        t_eq = time.perf_counter() - t0
+        return time.perf_counter() - t0
 
-    t_ransac = None
-    if hasattr(res, "ransac"):
-        res.ransac(stream)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            res.ransac(stream)
-        torch.cuda.synchronize()
-        t_ransac = time.perf_counter() - t0
+    t_stitch = extra(res.stitch)
+    res.warp(stream)            # leave the plain warped canvas in res.out for the byte count below
+    torch.cuda.synchronize()
+    t_eq = extra(res.equalize)
+    t_ransac = extra(res.ransac)
 
     # per-kernel durations, HIP events on the launch stream (rank-local)
     N.lib().apap_profile_enable(1)
     for _ in range(a.steps):
         res.solve(stream)
         res.warp(stream)
-        if t_eq is not None:
-            res.equalize(stream)
-        if t_ransac is not None:
-            res.ransac(stream)
+        res.equalize(stream)
+        res.ransac(stream)
     torch.cuda.synchronize()
-    ms = (ctypes.c_float * N.PROF_SLOTS)()
-    cnt = (ctypes.c_int * N.PROF_SLOTS)()
-    N.check(N.lib().apap_profile_read(ms, cnt))
+    kern = read_kernel_ms()
     N.lib().apap_profile_enable(0)
-    kern = {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(N.PROF_NAMES) if cnt[i] or i < 5}
+
+    # ------------------------------------------------------------------ cells: one pair sharded
+    cells_obj = None
+    if not a.no_cells:
+        from cvx_proj_amd.dist import ShardedSolver
+        cp = config_pair(a.cells_config, with_image=(rank == 0))
+        cs = ShardedSolver(cp, dev, dist)
+        barrier()
+        t0 = time.perf_counter()
+        cs.broadcast_inputs()           # once per pair: keypoint table + de-normalisation block from rank 0
+        barrier()
+        t_bcast = time.perf_counter() - t0
+        cs.solve()
+        barrier()
+        t0 = time.perf_counter()
+        cs.warp()                       # first call: the source image travels from rank 0 (set-up), then one warp
+        barrier()
+        t_first_warp = time.perf_counter() - t0
+        for _ in range(a.warmup):
+            cs.solve()
+            cs.warp()
+        tc_solve = timed(cs.solve, a.steps)
+        tc_warp = timed(cs.warp, a.steps)
+        assert int(cs.status.cpu()[0]) == 0
+        N.lib().apap_profile_enable(1)
+        for _ in range(min(a.steps, 10)):
+            cs.solve()
+            cs.warp()
+        torch.cuda.synchronize()
+        ckern = read_kernel_ms()
+        N.lib().apap_profile_enable(0)
+        c_flops = K1_FLOPS_PER_CELL_POINT * cs.n * cs.my_cells       # THIS rank's cells: what its K1 launch worked on
+        c_ach = c_flops / (ckern["assemble"] * 1e-3) / 1e12 if ckern.get("assemble") else None
+        cells_obj = {
+            "workload": f"{a.cells_config}: {CONFIGS[a.cells_config][0]}x{CONFIGS[a.cells_config][1]} pair, {cs.n} "
+                        f"correspondences, {cs.rows}x{cs.cols} mesh, canvas {cp.final_w}x{cp.final_h}; mesh rows and canvas "
+                        f"rows sharded over the ranks",
+            "world_size": world, "backend": ("rccl (nccl)" if backend == "nccl" else backend) if world > 1 else "none (1 rank)",
+            "scaling": "strong", "value": cs.cells_total * a.steps / tc_solve, "unit": "homographies/s",
+            "solve_ms_per_step": tc_solve / a.steps * 1e3,
+            "warp": {"value": cp.final_w * cp.final_h * a.steps / tc_warp / 1e6, "unit": "Mpix/s",
+                     "ms_per_step": tc_warp / a.steps * 1e3},
+            "table_broadcast_ms": t_bcast * 1e3, "first_warp_incl_image_broadcast_ms": t_first_warp * 1e3,
+            "collectives_per_step": "solve: 1 all-gather of the H grid (36 B per cell); warp: 1 all-gather of the canvas bands"
+                                    if world > 1 else "none",
+            "rank0_cells": cs.my_cells, "kernels_ms": ckern,
+            "roofline": None if c_ach is None else {
+                "kernel": "k_assemble (rank 0's shard)", "bound": "mfma", "achieved": c_ach, "peak": PEAK_FP64_TFLOPS,
+                "unit": "TFLOP/s", "frac": c_ach / PEAK_FP64_TFLOPS},
+        }
+        del cs
 
     if rank == 0:
-        local_cells = res.cells * getattr(res, "batch", 1)
-        flops = K1_FLOPS_PER_CELL_POINT * res.n * local_cells
+        flops = K1_FLOPS_PER_CELL_POINT * res.n * res.cells * res.batch          # rank 0's own launch
         t_k1 = kern["assemble"] * 1e-3
         achieved = flops / t_k1 / 1e12
-        resolved = "valu" if a.variant == "valu" else "mfma"      # auto = mfma (apap_kernels.hip plan_solve)
+        resolved = "mfma" if a.variant == "auto" else a.variant      # auto = mfma (apap_kernels.hip plan_solve)
         # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes
         # (tools/profile.sh) and committed under profiles/: (2 x FETCH_SIZE + WRITE_SIZE) KiB,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads.
@@ -344,27 +515,35 @@ def main():
             traffic_warp = tj.get(f"{a.config}:k_warp_rows", tj.get(f"{a.config}:k_warp"))
         # K3 (HBM-bound half of the metric): 6 B per in-range pixel, 3 B per blank one
         out_pixels = pair.final_w * pair.final_h
-        nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu()) if a.mode == "pairs" or world == 1 else None
-        warp_bytes = (6 * nz + 3 * (out_pixels - nz)) if nz is not None else None
+        nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu())
+        warp_bytes = 6 * nz + 3 * (out_pixels - nz)
+        pairs_obj = {"workload": f"{a.config} x {world} (one pair per rank)", "world_size": world, "scaling": "weak",
+                     "value": units_solve * a.steps / t_solve, "unit": "homographies/s",
+                     "solve_ms_per_step": t_solve / a.steps * 1e3,
+                     "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
+                              "ms_per_step": t_warp / a.steps * 1e3},
+                     "collectives_per_step": "none (independent pairs)"}
         line = {
             "metric": METRIC, "value": units_solve * a.steps / t_solve, "unit": "homographies/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": (t_solve + t_warp) / a.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "ms_per_step": (t_solve + t_warp) / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.config}: {CONFIGS[a.config][0]}x{CONFIGS[a.config][1]} pair, "
                                    f"{res.n} correspondences, {res.rows}x{res.cols} mesh, canvas "
-                                   f"{pair.final_w}x{pair.final_h}", "mode": a.mode, "variant": a.variant,
+                                   f"{pair.final_w}x{pair.final_h}", "mode": "pairs", "variant": a.variant,
                        "pairs_per_solve_launch": a.batch,
                        "launch": "hip graph replay" if a.graph else "eager",
-                       "parallelism": f"{a.mode}x{world}"},
+                       "parallelism": f"pairsx{world}"},
             "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
                      "ms_per_step": t_warp / a.steps * 1e3},
             "solve_ms_per_step": t_solve / a.steps * 1e3,
-            "stitch": None if t_stitch is None else {
+            "pairs": pairs_obj,
+            "cells": cells_obj,
+            "stitch": {
                 "value": pair.final_w * pair.final_h * a.steps / t_stitch / 1e6, "unit": "Mpix/s (rank 0)",
                 "ms_per_step": t_stitch / a.steps * 1e3,
                 "note": "fused warp + paste + uniform_blend, apap.py:258-262; extra, not in `value`"},
-            "equalize": None if t_eq is None else {
+            "equalize": {
                 "value": pair.shape[0] * pair.shape[1] * a.steps / t_eq / 1e6, "unit": "Mpix/s (rank 0)",
                 "ms_per_step": t_eq / a.steps * 1e3,
                 "roofline": {"kernels": "k_eq_hist + k_eq_apply", "bound": "hbm",
@@ -373,7 +552,7 @@ def main():
                              "frac": 3.0 * pair.img.size / ((kern["eq_hist"] + kern["eq_apply"]) * 1e-3) / 1e9 / PEAK_HBM_GBS},
                 "note": "per-channel cv.equalizeHist of the 4K source image, utils.py:85-91; algorithmic "
                         "traffic 3 bytes per image byte (read, read, write); extra, not in `value`"},
-            "ransac": None if t_ransac is None else {
+            "ransac": {
                 "ms_per_call": t_ransac / a.steps * 1e3, "hypotheses": N.RANSAC_ITERATIONS, "points": res.n,
                 "inliers": int(res.r_res.cpu()[1]),
                 "note": "device half of the seed homography (4-point hypotheses, 5 px), baseline_stitch_test.py:42; "
@@ -383,18 +562,21 @@ def main():
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "hbm_gbs": None if traffic is None else traffic / t_k1 / 1e9,
-                         "note": "fp64 FMA work: the f64 matrix and vector pipes share one 78.6 TF datasheet "
-                                 "rate (54-59 TF sustained, profiles/r01_peak_fp64.txt); algorithmic 58 flop per "
-                                 "(cell, keypoint) counts sqrt and exp as one flop each, the kernel executes "
-                                 "~89 flops per pair for those 58 (DESIGN.md section 3)"},
-            "roofline_warp": None if warp_bytes is None else {
+                         "note": "fp64 work, issue-bound: no vector instruction co-executes with an f64 MFMA on gfx950 "
+                                 "(profiles/r02_coexec.txt), so the datasheet's single 78.6 TF figure covers the 32 "
+                                 "accumulation FMAs AND the ~20-instruction fp64 weight chain per (cell, keypoint), which "
+                                 "the algorithmic count prices at 58 flops; the kernel runs ~266 issue cycles per 64 "
+                                 "pairs whatever the MFMA shape (profiles/r02_k1_variants.txt, DESIGN.md section 3)"},
+            "roofline_warp": {
                 "kernel": "k_warp_rows", "bound": "hbm", "achieved": warp_bytes / (kern["warp"] * 1e-3) / 1e9,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (kern["warp"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "traffic": traffic_warp},
         }
-        if not a.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows,
-                                                min(a.cpu_pool, os.cpu_count() or 1))
+        if world == 1 and not a.no_call_level:
+            line["call_level"] = call_level(a.config)
+        if world == 1 and not a.no_cpu_baseline:
+            workers = usable_cores() if a.cpu_pool < 0 else a.cpu_pool
+            line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows, min(workers, 256))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

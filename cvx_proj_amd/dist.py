@@ -92,9 +92,11 @@ def hip_solve_batch(tables, denorms, vertices, gamma, sigma):
 class ShardedSolver:
     """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
 
-    ``solve()`` = broadcast of the keypoint table from rank 0, local solve of this rank's
-    rows, all-gather of the H grid; afterwards ``self.H`` holds the full grid on every
-    rank (what a following sharded warp needs for its own rows, and what rank 0 writes).
+    ``broadcast_inputs()`` = the once-per-pair exchange: the keypoint table and the
+    de-normalisation block go from rank 0 to everyone (``solve()`` does it on its first call if
+    the caller has not).  ``solve()`` = local solve of this rank's rows + all-gather of the H
+    grid; afterwards ``self.H`` holds the full grid on every rank (what a following sharded
+    warp needs for its own rows, and what rank 0 writes).
     """
 
     def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows):
@@ -121,12 +123,22 @@ class ShardedSolver:
         self._mine = torch.zeros((self.max_rows * self.cols, 9), dtype=torch.float32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.cells = self.cells_total
+        self.my_cells = (b - a) * self.cols          # what this rank's kernels work on
+        self._inputs_sent = False
 
-    def solve(self, stream=None):
+    def broadcast_inputs(self):
+        """Keypoint table (n x 256 B) and de-normalisation block from rank 0 to every rank:
+        once per pair, not once per solve."""
         d = self.dist
         if d is not None and self.world > 1:
             d.broadcast(self.table, src=0)
             d.broadcast(self.denorm, src=0)
+        self._inputs_sent = True
+
+    def solve(self, stream=None):
+        d = self.dist
+        if not self._inputs_sent:
+            self.broadcast_inputs()
         a, b = self.my_rows
         mine = self.solve_fn(self.table, self.denorm, self.vert, self.pair.gamma, self.pair.sigma)
         if d is None or self.world == 1:
@@ -169,12 +181,12 @@ class ShardedSolver:
             self._warp_setup()
         p, d = self.pair, self.dist
         a, b = self.bands[self.rank]
+        single = d is None or self.world == 1
         st = self.warp_fn(self.img, self.H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
-                          self._band, (self.rows, self.cols))
+                          self.out if single else self._band, (self.rows, self.cols))     # one rank: straight into the canvas
         if st is not None:
             self.status = st
-        if d is None or self.world == 1:
-            self.out.copy_(self._band[:b - a])
+        if single:
             return self.out
         if all(rb - ra == b - a for ra, rb in self.bands):
             d.all_gather_into_tensor(self.out, self._band[:b - a])

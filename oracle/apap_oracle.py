@@ -221,8 +221,9 @@ def _pool_worker(args):
     return [(i, j, H[i, j]) for i, j in cells]
 
 
-def _pool_ready(_):
-    return 0
+def _pool_init(counter):
+    with counter.get_lock():
+        counter.value += 1
 
 
 def local_homography_pool(src_point, dst_point, vertices, gamma, sigma, cells, workers):
@@ -233,8 +234,10 @@ def local_homography_pool(src_point, dst_point, vertices, gamma, sigma, cells, w
     import time
     chunks = [cells[k::workers] for k in range(workers)]
     ctx = mp.get_context("spawn")      # never fork a process that has initialised the GPU
-    with ctx.Pool(workers) as pool:
-        pool.map(_pool_ready, range(4 * workers))
+    ready = ctx.Value("i", 0)
+    with ctx.Pool(workers, initializer=_pool_init, initargs=(ready,)) as pool:
+        while ready.value < workers:   # every worker has started and imported this module (numpy with it)
+            time.sleep(0.01)
         t0 = time.perf_counter()
         parts = pool.map(_pool_worker, [(src_point, dst_point, vertices, gamma, sigma, c) for c in chunks if c])
         seconds = time.perf_counter() - t0

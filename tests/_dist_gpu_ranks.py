@@ -1,0 +1,48 @@
+"""Rank program of tests/test_gpu_dist.py: ShardedSolver with the real HIP engine on every rank.
+Launched by torch.distributed.run; the backend is gloo when the ranks have to share one GPU (RCCL
+refuses two ranks on one device), nccl when every rank has its own."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, cfg = sys.argv[1], sys.argv[2]
+    rank, world, local = (int(os.environ[k]) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % ndev)
+    torch.cuda.set_device(dev)
+    if ndev >= world:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    from cvx_proj_amd.dist import ShardedSolver, solve_pairs
+    from cvx_proj_amd.synth import config_pair
+    p = config_pair(cfg, with_image=(rank == 0))
+    s = ShardedSolver(p, dev, dist)
+    if rank != 0:
+        assert float(s.table.abs().sum()) == 0.0          # the table lives on rank 0 until the broadcast
+    H = s.solve().cpu().numpy().copy()
+    canvas = s.warp().cpu().numpy().copy()
+    H2 = s.solve().cpu().numpy()                          # a second solve does not broadcast again and gives the same grid
+    assert np.array_equal(H, H2)
+    pairs = [config_pair("C1", with_image=False, seed_offset=k) for k in range(5)]
+    grids = solve_pairs(pairs, dev, dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (H.tobytes(), canvas.tobytes()))
+    assert all(g == gathered[0] for g in gathered), "ranks disagree on the gathered grid / canvas"
+    if rank == 0:
+        np.savez(out_path, H=H, canvas=canvas, parts=np.array(s.parts), bands=np.array(s.bands),
+                 status=int(s.status.cpu()[0]), grids=np.stack(grids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

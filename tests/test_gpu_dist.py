@@ -1,0 +1,75 @@
+"""The multi-rank path with the real HIP engine: two and three ranks run
+ShardedSolver.solve() / warp() and solve_pairs; the gathered grid and canvas must equal the single-GPU
+ones bit for bit.  On a one-GPU box the ranks share the device and talk over gloo (RCCL refuses two
+ranks on one device); on a multi-GPU node the same program uses nccl = RCCL.  bench.py's own
+`--gpus 2` launch is rehearsed the same way."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cvx_proj_amd.synth import config_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def clean_env(**extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solver_ranks_equal_single_gpu(native, tmp_path, world):
+    out = str(tmp_path / "ranks.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_dist_gpu_ranks.py"), out, "C2"]
+    r = subprocess.run(cmd, env=clean_env(), capture_output=True, text=True, timeout=600)      # a child, never exec
+    assert r.returncode == 0, r.stderr[-3000:]
+    z = np.load(out)
+    p = config_pair("C2")
+    H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    assert np.array_equal(z["H"].reshape(H.shape), H)                     # row blocks + all-gather = the single-GPU grid
+    canvas, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    assert np.array_equal(z["canvas"], canvas)                            # row bands + all-gather = the single-GPU canvas
+    assert int(z["status"]) == 0
+    parts, bands = z["parts"], z["bands"]
+    assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == 100
+    assert len(bands) == world and bands[0][0] == 0 and bands[-1][1] == p.final_h
+    for k in range(5):                                                    # pairs dealt round-robin, gathered on rank 0
+        pk = config_pair("C1", with_image=False, seed_offset=k)
+        Hk, _ = native.local_homography(pk.src, pk.dst, pk.vertices, pk.gamma, pk.sigma, want_weights=False)
+        assert np.array_equal(z["grids"][k], Hk)
+
+
+def test_bench_self_launch_reports_pairs_and_cells(native):
+    """`python bench.py --gpus 2` (no torchrun around it): both sharding modes in the one JSON line,
+    each with the world size it saw; the cells leg's roofline is priced on rank 0's own shard."""
+    env = clean_env(APAP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--config", "C2", "--cells-config", "C2", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["mode"] == "pairs"
+    assert d["pairs"]["world_size"] == 2 and d["pairs"]["value"] == d["value"]
+    c = d["cells"]
+    assert c["world_size"] == 2 and c["scaling"] == "strong" and c["backend"] == "gloo"
+    assert c["rank0_cells"] == 50 * 100                               # half of the 100 x 100 mesh
+    assert 0.0 < c["roofline"]["frac"] < 1.0 and c["value"] > 0 and c["warp"]["value"] > 0
+    one = d["roofline"]["frac"]
+    assert c["roofline"]["frac"] < 2.5 * one                          # not inflated by the world size
