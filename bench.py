@@ -67,9 +67,10 @@ class Resident:
     """One image pair (or a batch of pairs sharing mesh and image) with everything the hot
     path reads resident in HBM."""
 
-    def __init__(self, pair, dev, batch=1, seed_pairs=None):
+    def __init__(self, pair, dev, batch=1, seed_pairs=None, ctx=None):
         self.pair = pair
         self.batch = batch
+        self.ctx = N._h(ctx)
         q = N.host_prepare(pair.src, pair.dst)
         table = N.host_build_table(pair.src, q["cf1"], q["cf2"])
         den = N.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
@@ -87,7 +88,7 @@ class Resident:
         self.table, self.den = t(table), t(den)
         self.vert = t(pair.vertices.reshape(-1, 2))
         self.H = torch.zeros((batch * self.cells, 9), dtype=torch.float32, device=dev)
-        self.work_bytes = max(N.lib().apap_solve_batch_workspace_bytes(self.n, self.cells, batch), 256)
+        self.work_bytes = max(N.lib().apap_solve_batch_workspace_bytes(self.ctx, self.n, self.cells, batch), 256)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=dev)
         self.img = t(pair.img)
         self.mesh_w, self.mesh_h = t(pair.mesh[0]), t(pair.mesh[1])
@@ -98,13 +99,13 @@ class Resident:
 
     def solve(self, stream):
         p = self.pair
-        N.check(N.lib().apap_solve_batch_device(self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, self.cells,
+        N.check(N.lib().apap_solve_batch_device(self.ctx, self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, self.cells,
                                                 p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(), self.batch,
                                                 self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
 
     def warp(self, stream):
         p = self.pair
-        N.check(N.lib().apap_warp_device(self.img.data_ptr(), p.shape[0], p.shape[1], self.H.data_ptr(), self.rows,
+        N.check(N.lib().apap_warp_device(self.ctx, self.img.data_ptr(), p.shape[0], p.shape[1], self.H.data_ptr(), self.rows,
                                          self.cols, self.mesh_w.data_ptr(), p.mesh.shape[1], self.mesh_h.data_ptr(),
                                          p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
                                          self.out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
@@ -117,7 +118,7 @@ class Resident:
         if not hasattr(self, "eq_out"):
             self.eq_out = torch.empty_like(self.img)
             self.eq_work = torch.zeros(N.lib().apap_equalize_workspace_bytes(3), dtype=torch.uint8, device=self.img.device)
-        N.check(N.lib().apap_equalize_hist_device(self.img.data_ptr(), p.shape[0], p.shape[1], 3, self.eq_out.data_ptr(),
+        N.check(N.lib().apap_equalize_hist_device(self.ctx, self.img.data_ptr(), p.shape[0], p.shape[1], 3, self.eq_out.data_ptr(),
                                                   self.eq_work.data_ptr(), self.eq_work.numel(), ctypes.c_void_p(stream)))
 
     def ransac(self, stream):
@@ -133,7 +134,7 @@ class Resident:
             self.r_H = torch.zeros(9, dtype=torch.float64, device=dev)
             self.r_mask = torch.zeros(self.n, dtype=torch.uint8, device=dev)
             self.r_res = torch.zeros(2, dtype=torch.int32, device=dev)
-        N.check(N.lib().apap_ransac_device(self.r_src.data_ptr(), self.r_dst.data_ptr(), self.n, 5.0, N.RANSAC_ITERATIONS,
+        N.check(N.lib().apap_ransac_device(self.ctx, self.r_src.data_ptr(), self.r_dst.data_ptr(), self.n, 5.0, N.RANSAC_ITERATIONS,
                                            ctypes.c_ulonglong(N.RANSAC_SEED), self.r_H.data_ptr(), self.r_mask.data_ptr(),
                                            self.r_res.data_ptr(), self.r_work.data_ptr(), self.r_wb,
                                            ctypes.c_void_p(stream)))
@@ -145,7 +146,7 @@ class Resident:
         if not hasattr(self, "center"):
             g = torch.Generator(device="cpu").manual_seed(1)
             self.center = torch.randint(0, 256, p.shape, dtype=torch.uint8, generator=g).to(self.img.device)
-        N.check(N.lib().apap_stitch_device(self.img.data_ptr(), p.shape[0], p.shape[1], self.center.data_ptr(),
+        N.check(N.lib().apap_stitch_device(self.ctx, self.img.data_ptr(), p.shape[0], p.shape[1], self.center.data_ptr(),
                                            p.shape[0], p.shape[1], self.H.data_ptr(), self.rows, self.cols,
                                            self.mesh_w.data_ptr(), p.mesh.shape[1], self.mesh_h.data_ptr(),
                                            p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
@@ -318,11 +319,10 @@ def selftest(rank, world):
 
 
 # --------------------------------------------------------------------------------------------- main
-def read_kernel_ms():
-    ms = (ctypes.c_float * N.PROF_SLOTS)()
-    cnt = (ctypes.c_int * N.PROF_SLOTS)()
-    N.check(N.lib().apap_profile_read(ms, cnt))
-    return {k: (ms[i] / max(cnt[i], 1)) for i, k in enumerate(N.PROF_NAMES) if cnt[i] or i < 5}
+def read_kernel_ms(ctx):
+    """Average milliseconds per launch of every kernel slot the context bracketed since the last read."""
+    prof = ctx.profile_read()
+    return {k: (ms / max(cnt, 1)) for i, (k, (ms, cnt)) in enumerate(prof.items()) if cnt or i < 5}
 
 
 def main():
@@ -342,6 +342,8 @@ def main():
                          "the warp half then runs once per pair")
     ap.add_argument("--graph", action="store_true",
                     help="capture the solve and the warp step into HIP graphs and time graph replays")
+    ap.add_argument("--want-waves", type=int, help="tuning: APAP_OPT_WANT_WAVES of the context (K1 keypoint splits)")
+    ap.add_argument("--warp-rows", type=int, choices=[0, 2, 4, 8], help="tuning: APAP_OPT_WARP_ROWS (0 = flat-order warp kernel)")
     ap.add_argument("--cpu-cells", type=int, default=40000)
     ap.add_argument("--cpu-rows", type=int, default=400)
     ap.add_argument("--cpu-pool", type=int, default=-1,
@@ -372,7 +374,11 @@ def main():
     else:
         dist = None
 
-    N.lib().apap_set_solver_variant(VARIANTS[a.variant])
+    ctx = N.Context(variant=VARIANTS[a.variant])        # options + profiling live in a context, not in the process
+    if a.want_waves:
+        ctx.set("want_waves", a.want_waves)
+    if a.warp_rows is not None:
+        ctx.set("warp_rows", a.warp_rows)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -398,7 +404,7 @@ def main():
     # ------------------------------------------------------------------ pairs: the headline
     pair = config_pair(a.config, seed_offset=rank * a.batch)
     extras = [config_pair(a.config, with_image=False, seed_offset=rank * a.batch + k) for k in range(1, a.batch)]
-    res = Resident(pair, dev, a.batch, extras)
+    res = Resident(pair, dev, a.batch, extras, ctx=ctx)
     units_solve = res.cells * a.batch * world
     units_warp = pair.final_w * pair.final_h * world
 
@@ -438,22 +444,22 @@ def main():
     t_ransac = extra(res.ransac)
 
     # per-kernel durations, HIP events on the launch stream (rank-local)
-    N.lib().apap_profile_enable(1)
+    ctx.set("profile", 1)
     for _ in range(a.steps):
         res.solve(stream)
         res.warp(stream)
         res.equalize(stream)
         res.ransac(stream)
     torch.cuda.synchronize()
-    kern = read_kernel_ms()
-    N.lib().apap_profile_enable(0)
+    kern = read_kernel_ms(ctx)
+    ctx.set("profile", 0)
 
     # ------------------------------------------------------------------ cells: one pair sharded
     cells_obj = None
     if not a.no_cells:
         from cvx_proj_amd.dist import ShardedSolver
         cp = config_pair(a.cells_config, with_image=(rank == 0))
-        cs = ShardedSolver(cp, dev, dist)
+        cs = ShardedSolver(cp, dev, dist, ctx=ctx)
         barrier()
         t0 = time.perf_counter()
         cs.broadcast_inputs()           # once per pair: keypoint table + de-normalisation block from rank 0
@@ -471,13 +477,13 @@ def main():
         tc_solve = timed(cs.solve, a.steps)
         tc_warp = timed(cs.warp, a.steps)
         assert int(cs.status.cpu()[0]) == 0
-        N.lib().apap_profile_enable(1)
+        ctx.set("profile", 1)
         for _ in range(min(a.steps, 10)):
             cs.solve()
             cs.warp()
         torch.cuda.synchronize()
-        ckern = read_kernel_ms()
-        N.lib().apap_profile_enable(0)
+        ckern = read_kernel_ms(ctx)
+        ctx.set("profile", 0)
         c_flops = K1_FLOPS_PER_CELL_POINT * cs.n * cs.my_cells       # THIS rank's cells: what its K1 launch worked on
         c_ach = c_flops / (ckern["assemble"] * 1e-3) / 1e12 if ckern.get("assemble") else None
         cells_obj = {

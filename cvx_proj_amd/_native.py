@@ -24,14 +24,37 @@ TABLE_STRIDE = 32
 DENORM_DOUBLES = 36
 VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1, 2, 3, 4
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
+# options of a context (include/apap_hip.h)
+OPT_SOLVER_VARIANT, OPT_EIGEN_SOLVER, OPT_CAREFUL, OPT_PROFILE, OPT_WANT_WAVES, OPT_WARP_ROWS, OPT_WEIGHT_CHUNK_KB = range(7)
 
 
 class ApapError(RuntimeError):
-    """A native call failed; ``code`` is one of the APAP_ERR_* values."""
+    """A native call failed; ``code`` is one of the APAP_ERR_* values.  The conditions the
+    reference signals with a specific Python exception raise a subclass that is ALSO that
+    exception, so ``except np.linalg.LinAlgError`` / ``except IndexError`` / ``except ValueError``
+    around the reference's class keep working around this one."""
 
     def __init__(self, code, message):
         super().__init__(f"[apap_hip error {code}] {message}")
         self.code = code
+
+
+class ApapSingularError(ApapError, np.linalg.LinAlgError):
+    """APAP_ERR_SINGULAR: ``numpy.linalg.inv`` of a cell raised LinAlgError("Singular matrix")
+    (apap.py:165-166,203,252)."""
+
+
+class ApapIndexError(ApapError, IndexError):
+    """APAP_ERR_INDEX: ``np.where(i < mesh_h)[0][0]`` found no edge above a canvas index
+    (apap.py:207,209)."""
+
+
+class ApapValueError(ApapError, ValueError):
+    """APAP_ERR_INVALID_ARG: what the reference's shape unpacking rejects with ValueError
+    (apap.py:129-130,197,199)."""
+
+
+_ERROR_CLASSES = {ERR_SINGULAR: ApapSingularError, ERR_INDEX: ApapIndexError, ERR_INVALID_ARG: ApapValueError}
 
 
 _f32p = C.POINTER(C.c_float)
@@ -46,50 +69,55 @@ SIGNATURES = {
     "apap_last_error": (C.c_char_p, []),
     "apap_version": (C.c_char_p, []),
     "apap_device_count": (C.c_int, []),
-    "apap_set_solver_variant": (C.c_int, [C.c_int]),
-    "apap_set_eigen_solver": (C.c_int, [C.c_int]),
-    "apap_profile_enable": (C.c_int, [C.c_int]),
-    "apap_profile_read": (C.c_int, [_f32p, _i32p]),
+    "apap_ctx_create": (C.c_void_p, []),
+    "apap_ctx_destroy": (None, [_vp]),
+    "apap_ctx_set_option": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "apap_ctx_get_option": (C.c_int, [_vp, C.c_int, _i32p]),
+    "apap_ctx_profile_read": (C.c_int, [_vp, _f32p, _i32p]),
     "apap_host_prepare": (C.c_int, [_f32p, _f32p, C.c_int] + [_f32p] * 10),
     "apap_host_dlt_rows": (C.c_int, [_f32p, _f32p, C.c_int, _f32p]),
     "apap_host_build_table": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, _f64p]),
     "apap_host_build_denorm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f64p]),
-    "apap_local_homography": (C.c_int, [_f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
+    "apap_local_homography": (C.c_int, [_vp, _f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
                                         C.c_double, _f32p, _f64p, C.c_int]),
-    "apap_local_warp": (C.c_int, [_u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
+    "apap_local_warp": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
-    "apap_local_stitch": (C.c_int, [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p,
+    "apap_local_warp_f64": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _f64p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f64p, C.c_int]),
+    "apap_local_stitch": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p,
                                     C.c_int, _f64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
-    "apap_warp_coords": (C.c_int, [_f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int,
+    "apap_warp_coords": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, _f64p, C.c_int]),
-    "apap_invert_normalize_flatten": (C.c_int, [_f32p, C.c_int, _f64p, C.c_int]),
-    "apap_uniform_blend": (C.c_int, [_u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]),
-    "apap_solve_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "apap_solve_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp,
+    "apap_invert_normalize_flatten": (C.c_int, [_vp, _f32p, C.c_int, _f64p, C.c_int]),
+    "apap_uniform_blend": (C.c_int, [_vp, _u8p, _u8p, C.c_int, C.c_int, _u8p, C.c_int]),
+    "apap_solve_workspace_bytes": (C.c_size_t, [_vp, C.c_int, C.c_int]),
+    "apap_solve_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp, _vp,
                                     C.c_size_t, _vp]),
-    "apap_solve_batch_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "apap_solve_batch_device": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_double, C.c_double, _vp, _vp,
+    "apap_solve_batch_workspace_bytes": (C.c_size_t, [_vp, C.c_int, C.c_int, C.c_int]),
+    "apap_solve_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_double, C.c_double, _vp, _vp,
                                           C.c_int, _vp, C.c_size_t, _vp]),
-    "apap_weights_device": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp]),
+    "apap_weights_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp]),
     "apap_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "apap_warp_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
+    "apap_warp_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
-    "apap_warp_rows_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
+    "apap_warp_f64_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "apap_warp_rows_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp,
                                         _vp]),
-    "apap_stitch_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
+    "apap_stitch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
                                      _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
-    "apap_warp_coords_device": (C.c_int, [_vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
+    "apap_warp_coords_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp, _vp]),
-    "apap_flatten_device": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
-    "apap_blend_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "apap_equalize_hist": (C.c_int, [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
+    "apap_flatten_device": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp]),
+    "apap_blend_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "apap_equalize_hist": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "apap_equalize_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "apap_equalize_hist_device": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
-    "apap_find_homography_ransac": (C.c_int, [_f32p, _f32p, C.c_int, C.c_double, C.c_int, C.c_ulonglong, _f64p, _u8p,
+    "apap_equalize_hist_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp]),
+    "apap_find_homography_ransac": (C.c_int, [_vp, _f32p, _f32p, C.c_int, C.c_double, C.c_int, C.c_ulonglong, _f64p, _u8p,
                                               _i32p, C.c_int]),
     "apap_ransac_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "apap_ransac_device": (C.c_int, [_vp, _vp, C.c_int, C.c_double, C.c_int, C.c_ulonglong, _vp, _vp, _vp, _vp,
+    "apap_ransac_device": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, C.c_ulonglong, _vp, _vp, _vp, _vp,
                                      C.c_size_t, _vp]),
 }
 
@@ -124,7 +152,62 @@ def lib():
 
 def check(code):
     if code != OK:
-        raise ApapError(code, lib().apap_last_error().decode("utf-8", "replace"))
+        raise _ERROR_CLASSES.get(code, ApapError)(code, lib().apap_last_error().decode("utf-8", "replace"))
+
+
+class Context:
+    """``apap_ctx`` of include/apap_hip.h: solver options, per-kernel profiling and the pool of
+    device buffers that host-buffer calls reuse.  The library has no process-wide mutable state;
+    pass a context as ``ctx=`` to any wrapper below (``None`` = built-in defaults).  Not to be
+    shared between threads; use one per thread."""
+
+    def __init__(self, **options):
+        self._h = lib().apap_ctx_create()
+        if not self._h:
+            raise ApapError(ERR_HIP, "apap_ctx_create failed")
+        for k, v in options.items():
+            self.set(k, v)
+
+    _NAMES = {"variant": OPT_SOLVER_VARIANT, "eigen": OPT_EIGEN_SOLVER, "careful": OPT_CAREFUL, "profile": OPT_PROFILE,
+              "want_waves": OPT_WANT_WAVES, "warp_rows": OPT_WARP_ROWS, "weight_chunk_kb": OPT_WEIGHT_CHUNK_KB}
+
+    def set(self, name, value):
+        check(lib().apap_ctx_set_option(self._h, self._NAMES[name], int(value)))
+        return self
+
+    def get(self, name):
+        v = C.c_int(0)
+        check(lib().apap_ctx_get_option(self._h, self._NAMES[name], C.byref(v)))
+        return v.value
+
+    def profile_read(self):
+        """``{kernel slot name: (milliseconds, launches)}`` since the previous read."""
+        ms = (C.c_float * PROF_SLOTS)()
+        cnt = (C.c_int * PROF_SLOTS)()
+        check(lib().apap_ctx_profile_read(self._h, ms, cnt))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(PROF_NAMES)}
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            lib().apap_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def _h(ctx):
+    """ctypes handle of ``ctx`` (a Context, a raw handle, or None)."""
+    if ctx is None:
+        return None
+    return C.c_void_p(ctx.handle if isinstance(ctx, Context) else ctx)
 
 
 def last_error():
@@ -187,7 +270,7 @@ def host_build_denorm(iC2, C1, iN2, N1):
 
 
 # ---------------------------------------------------------------- host-buffer compute
-def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device=-1):
+def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device=-1, ctx=None):
     src = as_f32(src, (2,))
     dst = as_f32(dst, (2,))
     if src.ndim != 2 or src.shape != dst.shape:
@@ -199,31 +282,44 @@ def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device
     n = src.shape[0]
     H = np.empty((rows, cols, 3, 3), np.float32)
     W = np.empty((rows, cols, n), np.float64) if want_weights else None
-    check(lib().apap_local_homography(_ptr(src, C.c_float), _ptr(dst, C.c_float), n, _ptr(vertices, C.c_double),
+    check(lib().apap_local_homography(_h(ctx), _ptr(src, C.c_float), _ptr(dst, C.c_float), n, _ptr(vertices, C.c_double),
                                       rows, cols, float(gamma), float(sigma), _ptr(H, C.c_float),
                                       _ptr(W, C.c_double), device))
     return H, W
 
 
-def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=True, device=-1):
+def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=True, device=-1, ctx=None):
     img = np.ascontiguousarray(img, dtype=np.uint8)
     img_h, img_w, ch = img.shape
     if ch != 3:
         raise ValueError(f"image must be (h, w, 3); got {img.shape}")
-    H = as_f32(H, (3, 3))
-    rows, cols = H.shape[:2]
     mesh_w = np.ascontiguousarray(mesh_w, dtype=np.float64)
     mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
     out = np.empty((final_h, final_w, 3), np.uint8)
+    if isinstance(H, np.ndarray) and H.dtype == np.float64:
+        # the reference inverts and multiplies in the grid's own dtype (apap.py:201-203,210-213): a
+        # float64 grid is not rounded to float32 on the way
+        H = np.ascontiguousarray(H)
+        if H.shape[-2:] != (3, 3):
+            raise ValueError(f"expected trailing shape (3, 3), got {H.shape}")
+        rows, cols = H.shape[:2]
+        Hinv = np.empty_like(H) if want_inverse else None
+        check(lib().apap_local_warp_f64(_h(ctx), _ptr(img, C.c_uint8), img_h, img_w, _ptr(H, C.c_double), rows, cols,
+                                        _ptr(mesh_w, C.c_double), mesh_w.size, _ptr(mesh_h, C.c_double), mesh_h.size,
+                                        int(final_w), int(final_h), int(off_x), int(off_y), _ptr(out, C.c_uint8),
+                                        _ptr(Hinv, C.c_double), device))
+        return out, Hinv
+    H = as_f32(H, (3, 3))
+    rows, cols = H.shape[:2]
     Hinv = np.empty_like(H) if want_inverse else None
-    check(lib().apap_local_warp(_ptr(img, C.c_uint8), img_h, img_w, _ptr(H, C.c_float), rows, cols,
+    check(lib().apap_local_warp(_h(ctx), _ptr(img, C.c_uint8), img_h, img_w, _ptr(H, C.c_float), rows, cols,
                                 _ptr(mesh_w, C.c_double), mesh_w.size, _ptr(mesh_h, C.c_double), mesh_h.size,
                                 int(final_w), int(final_h), int(off_x), int(off_y), _ptr(out, C.c_uint8),
                                 _ptr(Hinv, C.c_float), device))
     return out, Hinv
 
 
-def local_stitch(img, center, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=False, device=-1):
+def local_stitch(img, center, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=False, device=-1, ctx=None):
     """Fused local_warp + paste of ``center`` at the offsets + uniform_blend."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     center = np.ascontiguousarray(center, dtype=np.uint8)
@@ -235,7 +331,7 @@ def local_stitch(img, center, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y,
     mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
     out = np.empty((final_h, final_w, 3), np.uint8)
     Hinv = np.empty_like(H) if want_inverse else None
-    check(lib().apap_local_stitch(_ptr(img, C.c_uint8), img.shape[0], img.shape[1], _ptr(center, C.c_uint8),
+    check(lib().apap_local_stitch(_h(ctx), _ptr(img, C.c_uint8), img.shape[0], img.shape[1], _ptr(center, C.c_uint8),
                                   center.shape[0], center.shape[1], _ptr(H, C.c_float), rows, cols,
                                   _ptr(mesh_w, C.c_double), mesh_w.size, _ptr(mesh_h, C.c_double), mesh_h.size,
                                   int(final_w), int(final_h), int(off_x), int(off_y), _ptr(out, C.c_uint8),
@@ -243,45 +339,45 @@ def local_stitch(img, center, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y,
     return out, Hinv
 
 
-def warp_coords(H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, device=-1):
+def warp_coords(H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, device=-1, ctx=None):
     H = as_f32(H, (3, 3))
     rows, cols = H.shape[:2]
     mesh_w = np.ascontiguousarray(mesh_w, dtype=np.float64)
     mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
     coords = np.empty((final_h, final_w, 2), np.float64)
-    check(lib().apap_warp_coords(_ptr(H, C.c_float), rows, cols, _ptr(mesh_w, C.c_double), mesh_w.size,
+    check(lib().apap_warp_coords(_h(ctx), _ptr(H, C.c_float), rows, cols, _ptr(mesh_w, C.c_double), mesh_w.size,
                                  _ptr(mesh_h, C.c_double), mesh_h.size, int(final_w), int(final_h), int(off_x),
                                  int(off_y), _ptr(coords, C.c_double), device))
     return coords
 
 
-def invert_normalize_flatten(H, device=-1):
+def invert_normalize_flatten(H, device=-1, ctx=None):
     H = as_f32(H, (3, 3))
     cells = H.size // 9
     out = np.empty((cells, 9), np.float64)
-    check(lib().apap_invert_normalize_flatten(_ptr(H, C.c_float), cells, _ptr(out, C.c_double), device))
+    check(lib().apap_invert_normalize_flatten(_h(ctx), _ptr(H, C.c_float), cells, _ptr(out, C.c_double), device))
     return out
 
 
-def uniform_blend(img1, img2, device=-1):
+def uniform_blend(img1, img2, device=-1, ctx=None):
     a = np.ascontiguousarray(img1, dtype=np.uint8)
     b = np.ascontiguousarray(img2, dtype=np.uint8)
     if a.shape != b.shape or a.ndim != 3 or a.shape[2] != 3:
         raise ValueError(f"images must share shape (h, w, 3); got {a.shape} and {b.shape}")
     out = np.empty_like(a)
-    check(lib().apap_uniform_blend(_ptr(a, C.c_uint8), _ptr(b, C.c_uint8), a.shape[0], a.shape[1],
+    check(lib().apap_uniform_blend(_h(ctx), _ptr(a, C.c_uint8), _ptr(b, C.c_uint8), a.shape[0], a.shape[1],
                                    _ptr(out, C.c_uint8), device))
     return out
 
 
-def equalize_hist(img, device=-1):
+def equalize_hist(img, device=-1, ctx=None):
     """Per-channel ``cv.equalizeHist`` of an (h, w) or (h, w, c) uint8 image, c <= 4."""
     a = np.ascontiguousarray(img, dtype=np.uint8)
     if a.ndim not in (2, 3) or (a.ndim == 3 and not 1 <= a.shape[2] <= 4) or a.size == 0:
         raise ValueError(f"image must be (h, w) or (h, w, 1..4) uint8 and non-empty; got {a.shape}")
     channels = 1 if a.ndim == 2 else a.shape[2]
     out = np.empty_like(a)
-    check(lib().apap_equalize_hist(_ptr(a, C.c_uint8), a.shape[0], a.shape[1], channels, _ptr(out, C.c_uint8), device))
+    check(lib().apap_equalize_hist(_h(ctx), _ptr(a, C.c_uint8), a.shape[0], a.shape[1], channels, _ptr(out, C.c_uint8), device))
     return out
 
 
@@ -289,7 +385,7 @@ RANSAC_ITERATIONS = 2048                 # include/apap_hip.h
 RANSAC_SEED = 0x5EEDC0DE5EEDC0DE
 
 
-def find_homography_ransac(src, dst, thresh=5.0, iterations=RANSAC_ITERATIONS, seed=RANSAC_SEED, device=-1):
+def find_homography_ransac(src, dst, thresh=5.0, iterations=RANSAC_ITERATIONS, seed=RANSAC_SEED, device=-1, ctx=None):
     """``cv.findHomography(src, dst, cv.RANSAC, thresh)``: ``(H (3, 3) float64 or None, mask (n, 1) uint8)``."""
     s = np.ascontiguousarray(src, dtype=np.float32).reshape(-1, 2)
     d = np.ascontiguousarray(dst, dtype=np.float32).reshape(-1, 2)
@@ -298,7 +394,7 @@ def find_homography_ransac(src, dst, thresh=5.0, iterations=RANSAC_ITERATIONS, s
     H = np.zeros(9, dtype=np.float64)
     mask = np.zeros(len(s), dtype=np.uint8)
     inliers = C.c_int(0)
-    check(lib().apap_find_homography_ransac(_ptr(s, C.c_float), _ptr(d, C.c_float), len(s), float(thresh), int(iterations),
+    check(lib().apap_find_homography_ransac(_h(ctx), _ptr(s, C.c_float), _ptr(d, C.c_float), len(s), float(thresh), int(iterations),
                                             C.c_ulonglong(seed), _ptr(H, C.c_double), _ptr(mask, C.c_uint8),
                                             C.byref(inliers), device))
     if inliers.value < 4:

@@ -31,12 +31,13 @@ class APAP:
     """As-Projective-As-Possible moving-DLT engine (GPU).  Constructor and method
     signatures follow reference apap.py:21-217."""
 
-    def __init__(self, gamma, sigma, final_size, offset, device=-1):
+    def __init__(self, gamma, sigma, final_size, offset, device=-1, ctx=None):
         self.gamma = gamma
         self.sigma = sigma
         self.final_width, self.final_height = final_size
         self.offset_x, self.offset_y = offset
         self.device = device
+        self.ctx = ctx          # a _native.Context (solver options, profiling); None = the defaults
 
     # ---- once-per-pair helpers: numpy, same arithmetic as the reference -------------
     @staticmethod
@@ -98,7 +99,7 @@ class APAP:
         bytes per cell of HBM and PCIe traffic and the reference's own caller never
         reads it (apap.py:242)."""
         return _native.local_homography(src_point, dst_point, vertices, self.gamma, self.sigma,
-                                        want_weights=return_weights, device=self.device)
+                                        want_weights=return_weights, device=self.device, ctx=self.ctx)
 
     # ---- hot loop 2 ------------------------------------------------------------------
     def local_warp(self, ori_img, local_homography, mesh, progress=False):
@@ -114,7 +115,7 @@ class APAP:
         print("Inverse solving started.")        # the reference prints these two lines (apap.py:200,204);
         warped, hinv = _native.local_warp(ori_img, local_homography, mesh_w, mesh_h, self.final_width,
                                           self.final_height, self.offset_x, self.offset_y,
-                                          want_inverse=True, device=self.device)
+                                          want_inverse=True, device=self.device, ctx=self.ctx)
         print("Inverse solving completed.")      # here the inverses come from the same native call as the warp
         if isinstance(local_homography, np.ndarray) and local_homography.flags.writeable:
             local_homography[...] = hinv
@@ -128,7 +129,7 @@ class APAP:
         ``local_homography``."""
         mesh_w, mesh_h = mesh
         out, _ = _native.local_stitch(ori_img, center_img, local_homography, mesh_w, mesh_h, self.final_width,
-                                      self.final_height, self.offset_x, self.offset_y, device=self.device)
+                                      self.final_height, self.offset_x, self.offset_y, device=self.device, ctx=self.ctx)
         return out
 
 

@@ -23,20 +23,21 @@ thread_local char g_err[512] = "";
         if (e_ != hipSuccess) return apap::fail(APAP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
-// One pool per process, protected by a mutex: host entry points are serialised (the
-// reference is single-threaded; ctypes releases the GIL, so guard anyway).
-std::mutex g_mu;
+using namespace apap;   // DevSlot, S_* slot names
 
-struct Slot {
-    void *ptr = nullptr;
-    size_t cap = 0;
-    int dev = -1;
+// The device buffers that host-buffer calls reuse live in the caller's context.  Calls made with
+// a NULL context share this one pool (a cache: no option or result depends on it) and are
+// serialised on its mutex - the reference is single-threaded, ctypes releases the GIL, so guard.
+apap_ctx g_shared;
+
+struct PoolLock {
+    apap_ctx *pool;
+    std::unique_lock<std::mutex> lock;
+    explicit PoolLock(apap_ctx *ctx) : pool(ctx ? ctx : &g_shared), lock(pool->mu) {}
 };
-enum { S_TABLE, S_VERT, S_DENORM, S_H, S_WORK, S_W, S_IMG, S_OUT, S_MESHW, S_MESHH, S_HINV, S_STATUS, S_AUX, S_COUNT };
-Slot g_slots[S_COUNT];
 
-int slot_get(int which, size_t bytes, int dev, void **out) {
-    Slot &s = g_slots[which];
+int slot_get(apap_ctx *pool, int which, size_t bytes, int dev, void **out) {
+    DevSlot &s = pool->slots[which];
     if (bytes == 0) bytes = 4;
     if (s.ptr && (s.cap < bytes || s.dev != dev)) {
         (void)hipFree(s.ptr);
@@ -73,6 +74,13 @@ int select_device(int device, int *chosen) {
     return APAP_OK;
 }
 
+// Host-buffer calls enqueue copies from buffers they own (std::vector, stack arrays) on the null
+// stream; whatever way the function is left, the stream is drained before those buffers die.
+// Declare it AFTER the buffers it protects.
+struct SyncOnExit {
+    ~SyncOnExit() { (void)hipStreamSynchronize(nullptr); }
+};
+
 int status_to_code(int status, const char *who) {
     if (status & apap::kStatusSingular) return apap::fail(APAP_ERR_SINGULAR, "%s: Singular matrix", who);
     if (status & apap::kStatusIndex)
@@ -106,14 +114,14 @@ int apap_device_count(void) {
     return count;
 }
 
-int apap_local_homography(const float *src, const float *dst, int n, const double *vertices,
+int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int n, const double *vertices,
                           int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
                           double *W_out, int device) {
     if (!src || !dst || !vertices || !H_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: null argument");
     if (n < 2 || mesh_rows < 1 || mesh_cols < 1)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: n=%d mesh=%dx%d", n, mesh_rows, mesh_cols);
     if ((long long)mesh_rows * mesh_cols > (1ll << 30)) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: mesh too large");
-    std::lock_guard<std::mutex> lock(g_mu);
+    PoolLock pl(ctx);
     int dev;
     int rc = select_device(device, &dev);
     if (rc) return rc;
@@ -125,37 +133,37 @@ int apap_local_homography(const float *src, const float *dst, int n, const doubl
     if (rc) return rc;
     std::vector<double> table((size_t)n * APAP_TABLE_STRIDE);
     double denorm[APAP_DENORM_DOUBLES];
-    apap_host_build_table(src, cf1.data(), cf2.data(), n, table.data());
-    apap_host_build_denorm(iC2, C1, iN2, N1, denorm);
+    if ((rc = apap_host_build_table(src, cf1.data(), cf2.data(), n, table.data()))) return rc;
+    if ((rc = apap_host_build_denorm(iC2, C1, iN2, N1, denorm))) return rc;
+    const SyncOnExit drain;   // the async copies below read `table` and `denorm`
 
     const int cells = mesh_rows * mesh_cols;
-    const size_t work_bytes = apap_solve_workspace_bytes(n, cells);
+    const size_t work_bytes = apap_solve_workspace_bytes(ctx, n, cells);
     void *d_table, *d_vert, *d_denorm, *d_H, *d_work;
-    if ((rc = slot_get(S_TABLE, table.size() * sizeof(double), dev, &d_table))) return rc;
-    if ((rc = slot_get(S_VERT, (size_t)cells * 2 * sizeof(double), dev, &d_vert))) return rc;
-    if ((rc = slot_get(S_DENORM, sizeof(denorm), dev, &d_denorm))) return rc;
-    if ((rc = slot_get(S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
-    if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
+    if ((rc = slot_get(pl.pool, S_TABLE, table.size() * sizeof(double), dev, &d_table))) return rc;
+    if ((rc = slot_get(pl.pool, S_VERT, (size_t)cells * 2 * sizeof(double), dev, &d_vert))) return rc;
+    if ((rc = slot_get(pl.pool, S_DENORM, sizeof(denorm), dev, &d_denorm))) return rc;
+    if ((rc = slot_get(pl.pool, S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
+    if ((rc = slot_get(pl.pool, S_WORK, work_bytes, dev, &d_work))) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(d_vert, vertices, (size_t)cells * 2 * sizeof(double), hipMemcpyHostToDevice, nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(d_denorm, denorm, sizeof(denorm), hipMemcpyHostToDevice, nullptr));
-    rc = apap_solve_device((const double *)d_table, n, (const double *)d_vert, cells, gamma, sigma,
+    rc = apap_solve_device(ctx, (const double *)d_table, n, (const double *)d_vert, cells, gamma, sigma,
                            (const double *)d_denorm, (float *)d_H, d_work, work_bytes, nullptr);
     if (rc) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(H_out, d_H, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     if (W_out) {
         // stream the weight tensor through a bounded device buffer (it is 8 n bytes per cell)
-        // 1 GiB of device staging by default; APAP_W_CHUNK_BYTES lets tests force several chunks
-        const char *env = getenv("APAP_W_CHUNK_BYTES");
-        const size_t max_bytes = (env && atoll(env) > 0) ? (size_t)atoll(env) : ((size_t)1 << 30);
+        // 1 GiB of device staging by default; APAP_OPT_WEIGHT_CHUNK_KB lets tests force several chunks
+        const size_t max_bytes = (size_t)apap::opt(ctx, APAP_OPT_WEIGHT_CHUNK_KB) << 10;
         int chunk = (int)(max_bytes / ((size_t)n * sizeof(double)));
         if (chunk < 1) chunk = 1;
         if (chunk > cells) chunk = cells;
         void *d_W;
-        if ((rc = slot_get(S_W, (size_t)chunk * n * sizeof(double), dev, &d_W))) return rc;
+        if ((rc = slot_get(pl.pool, S_W, (size_t)chunk * n * sizeof(double), dev, &d_W))) return rc;
         for (int c0 = 0; c0 < cells; c0 += chunk) {
             const int nc = cells - c0 < chunk ? cells - c0 : chunk;
-            rc = apap_weights_device((const double *)d_table, n, (const double *)d_vert + (size_t)2 * c0, nc, gamma,
+            rc = apap_weights_device(ctx, (const double *)d_table, n, (const double *)d_vert + (size_t)2 * c0, nc, gamma,
                                      sigma, (double *)d_W, nullptr);
             if (rc) return rc;
             APAP_HIP_TRY(hipMemcpyAsync(W_out + (size_t)c0 * n, d_W, (size_t)nc * n * sizeof(double),
@@ -167,15 +175,16 @@ int apap_local_homography(const float *src, const float *dst, int n, const doubl
     return APAP_OK;
 }
 
-static int warp_common(const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
-                       int center_w, const float *Hfwd, int mesh_rows,
+// `h_bytes` = 4: the grid (and Hinv_out) is float32; 8: float64 (apap_local_warp_f64 only).
+static int warp_common(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
+                       int center_w, const void *Hfwd, size_t h_bytes, int mesh_rows,
                        int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
-                       int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
+                       int final_w, int final_h, int off_x, int off_y, uint8_t *out, void *Hinv_out,
                        double *coords, int device, const char *who) {
     if (!Hfwd || !mesh_w || !mesh_h) return apap::fail(APAP_ERR_INVALID_ARG, "%s: null argument", who);
     if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
         return apap::fail(APAP_ERR_INVALID_ARG, "%s: bad size", who);
-    std::lock_guard<std::mutex> lock(g_mu);
+    PoolLock pl(ctx);
     int dev;
     int rc = select_device(device, &dev);
     if (rc) return rc;
@@ -183,46 +192,51 @@ static int warp_common(const uint8_t *img, int img_h, int img_w, const uint8_t *
     const size_t work_bytes = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
     const size_t pixels = (size_t)final_w * final_h;
     void *d_H, *d_mw, *d_mh, *d_work, *d_status, *d_hinv = nullptr, *d_img = nullptr, *d_out = nullptr;
-    if ((rc = slot_get(S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
-    if ((rc = slot_get(S_MESHW, (size_t)n_w * sizeof(double), dev, &d_mw))) return rc;
-    if ((rc = slot_get(S_MESHH, (size_t)n_h * sizeof(double), dev, &d_mh))) return rc;
-    if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
-    if ((rc = slot_get(S_STATUS, sizeof(int), dev, &d_status))) return rc;
-    if (Hinv_out && (rc = slot_get(S_HINV, (size_t)cells * 9 * sizeof(float), dev, &d_hinv))) return rc;
+    if ((rc = slot_get(pl.pool, S_H, (size_t)cells * 9 * h_bytes, dev, &d_H))) return rc;
+    if ((rc = slot_get(pl.pool, S_MESHW, (size_t)n_w * sizeof(double), dev, &d_mw))) return rc;
+    if ((rc = slot_get(pl.pool, S_MESHH, (size_t)n_h * sizeof(double), dev, &d_mh))) return rc;
+    if ((rc = slot_get(pl.pool, S_WORK, work_bytes, dev, &d_work))) return rc;
+    if ((rc = slot_get(pl.pool, S_STATUS, sizeof(int), dev, &d_status))) return rc;
+    if (Hinv_out && (rc = slot_get(pl.pool, S_HINV, (size_t)cells * 9 * h_bytes, dev, &d_hinv))) return rc;
+    const SyncOnExit drain;   // `status` below is a stack variable the last copy writes
     APAP_HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), nullptr));
-    APAP_HIP_TRY(hipMemcpyAsync(d_H, Hfwd, (size_t)cells * 9 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_H, Hfwd, (size_t)cells * 9 * h_bytes, hipMemcpyHostToDevice, nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(d_mw, mesh_w, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice, nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(d_mh, mesh_h, (size_t)n_h * sizeof(double), hipMemcpyHostToDevice, nullptr));
     if (coords) {
-        if ((rc = slot_get(S_OUT, pixels * 2 * sizeof(double), dev, &d_out))) return rc;
-        rc = apap_warp_coords_device((const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w,
+        if ((rc = slot_get(pl.pool, S_OUT, pixels * 2 * sizeof(double), dev, &d_out))) return rc;
+        rc = apap_warp_coords_device(ctx, (const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w,
                                      (const double *)d_mh, n_h, final_w, final_h, off_x, off_y, (double *)d_out,
                                      d_work, work_bytes, (int *)d_status, nullptr);
         if (rc) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(coords, d_out, pixels * 2 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
     } else {
         const size_t img_bytes = (size_t)img_h * img_w * 3;
-        if ((rc = slot_get(S_IMG, img_bytes, dev, &d_img))) return rc;
-        if ((rc = slot_get(S_OUT, pixels * 3, dev, &d_out))) return rc;
+        if ((rc = slot_get(pl.pool, S_IMG, img_bytes, dev, &d_img))) return rc;
+        if ((rc = slot_get(pl.pool, S_OUT, pixels * 3, dev, &d_out))) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(d_img, img, img_bytes, hipMemcpyHostToDevice, nullptr));
         if (center) {
             void *d_center;
             const size_t cbytes = (size_t)center_h * center_w * 3;
-            if ((rc = slot_get(S_AUX, cbytes, dev, &d_center))) return rc;
+            if ((rc = slot_get(pl.pool, S_AUX, cbytes, dev, &d_center))) return rc;
             APAP_HIP_TRY(hipMemcpyAsync(d_center, center, cbytes, hipMemcpyHostToDevice, nullptr));
-            rc = apap_stitch_device((const uint8_t *)d_img, img_h, img_w, (const uint8_t *)d_center, center_h, center_w,
+            rc = apap_stitch_device(ctx, (const uint8_t *)d_img, img_h, img_w, (const uint8_t *)d_center, center_h, center_w,
                                     (const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w,
                                     (const double *)d_mh, n_h, final_w, final_h, off_x, off_y, (uint8_t *)d_out,
                                     (float *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
+        } else if (h_bytes == sizeof(double)) {
+            rc = apap_warp_f64_device(ctx, (const uint8_t *)d_img, img_h, img_w, (const double *)d_H, mesh_rows, mesh_cols,
+                                      (const double *)d_mw, n_w, (const double *)d_mh, n_h, final_w, final_h, off_x, off_y,
+                                      (uint8_t *)d_out, (double *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
         } else {
-            rc = apap_warp_device((const uint8_t *)d_img, img_h, img_w, (const float *)d_H, mesh_rows, mesh_cols,
+            rc = apap_warp_device(ctx, (const uint8_t *)d_img, img_h, img_w, (const float *)d_H, mesh_rows, mesh_cols,
                                   (const double *)d_mw, n_w, (const double *)d_mh, n_h, final_w, final_h, off_x, off_y,
                                   (uint8_t *)d_out, (float *)d_hinv, d_work, work_bytes, (int *)d_status, nullptr);
         }
         if (rc) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(out, d_out, pixels * 3, hipMemcpyDeviceToHost, nullptr));
         if (Hinv_out)
-            APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+            APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * h_bytes, hipMemcpyDeviceToHost, nullptr));
     }
     int status = 0;
     APAP_HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, nullptr));
@@ -230,100 +244,111 @@ static int warp_common(const uint8_t *img, int img_h, int img_w, const uint8_t *
     return status_to_code(status, who);
 }
 
-int apap_local_warp(const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
+int apap_local_warp(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
                     int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
                     int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
                     int device) {
     if (!img || !out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp: null image");
     if (img_h < 1 || img_w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp: bad image size");
-    return warp_common(img, img_h, img_w, nullptr, 0, 0, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w,
-                       final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_warp");
+    return warp_common(ctx, img, img_h, img_w, nullptr, 0, 0, Hfwd, sizeof(float), mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h,
+                       final_w, final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_warp");
 }
 
-int apap_local_stitch(const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
+int apap_local_warp_f64(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const double *Hfwd, int mesh_rows,
+                        int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
+                        int final_w, int final_h, int off_x, int off_y, uint8_t *out, double *Hinv_out,
+                        int device) {
+    if (!img || !out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp_f64: null image");
+    if (img_h < 1 || img_w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_warp_f64: bad image size");
+    return warp_common(ctx, img, img_h, img_w, nullptr, 0, 0, Hfwd, sizeof(double), mesh_rows, mesh_cols, mesh_w, n_w, mesh_h,
+                       n_h, final_w, final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_warp_f64");
+}
+
+int apap_local_stitch(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
                       int center_w, const float *Hfwd, int mesh_rows, int mesh_cols,
                       const double *mesh_w, int n_w, const double *mesh_h, int n_h, int final_w,
                       int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out, int device) {
     if (!img || !out || !center) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_stitch: null image");
     if (img_h < 1 || img_w < 1 || center_h < 1 || center_w < 1)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_stitch: bad image size");
-    return warp_common(img, img_h, img_w, center, center_h, center_w, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h,
-                       n_h, final_w, final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_stitch");
+    return warp_common(ctx, img, img_h, img_w, center, center_h, center_w, Hfwd, sizeof(float), mesh_rows, mesh_cols, mesh_w, n_w,
+                       mesh_h, n_h, final_w, final_h, off_x, off_y, out, Hinv_out, nullptr, device, "apap_local_stitch");
 }
 
-int apap_warp_coords(const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
+int apap_warp_coords(apap_ctx *ctx, const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
                      const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
                      double *coords, int device) {
     if (!coords) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_coords: null output");
-    return warp_common(nullptr, 0, 0, nullptr, 0, 0, Hfwd, mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w,
-                       final_h, off_x, off_y, nullptr, nullptr, coords, device, "apap_warp_coords");
+    return warp_common(ctx, nullptr, 0, 0, nullptr, 0, 0, Hfwd, sizeof(float), mesh_rows, mesh_cols, mesh_w, n_w, mesh_h, n_h,
+                       final_w, final_h, off_x, off_y, nullptr, nullptr, coords, device, "apap_warp_coords");
 }
 
-int apap_invert_normalize_flatten(const float *H, int cells, double *out, int device) {
+int apap_invert_normalize_flatten(apap_ctx *ctx, const float *H, int cells, double *out, int device) {
     if (!H || !out || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_invert_normalize_flatten: bad argument");
-    std::lock_guard<std::mutex> lock(g_mu);
+    PoolLock pl(ctx);
     int dev;
     int rc = select_device(device, &dev);
     if (rc) return rc;
     void *d_H, *d_out, *d_status;
-    if ((rc = slot_get(S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
-    if ((rc = slot_get(S_AUX, (size_t)cells * 9 * sizeof(double), dev, &d_out))) return rc;
-    if ((rc = slot_get(S_STATUS, sizeof(int), dev, &d_status))) return rc;
+    if ((rc = slot_get(pl.pool, S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
+    if ((rc = slot_get(pl.pool, S_AUX, (size_t)cells * 9 * sizeof(double), dev, &d_out))) return rc;
+    if ((rc = slot_get(pl.pool, S_STATUS, sizeof(int), dev, &d_status))) return rc;
+    int status = 0;
+    const SyncOnExit drain;
     APAP_HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(d_H, H, (size_t)cells * 9 * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    rc = apap_flatten_device((const float *)d_H, cells, (double *)d_out, (int *)d_status, nullptr);
+    rc = apap_flatten_device(ctx, (const float *)d_H, cells, (double *)d_out, (int *)d_status, nullptr);
     if (rc) return rc;
-    int status = 0;
     APAP_HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)cells * 9 * sizeof(double), hipMemcpyDeviceToHost, nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(&status, d_status, sizeof(int), hipMemcpyDeviceToHost, nullptr));
     APAP_HIP_TRY(hipStreamSynchronize(nullptr));
     return status_to_code(status, "apap_invert_normalize_flatten");
 }
 
-int apap_uniform_blend(const uint8_t *img1, const uint8_t *img2, int h, int w, uint8_t *out,
+int apap_uniform_blend(apap_ctx *ctx, const uint8_t *img1, const uint8_t *img2, int h, int w, uint8_t *out,
                        int device) {
     if (!img1 || !img2 || !out || h < 1 || w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_uniform_blend: bad argument");
-    std::lock_guard<std::mutex> lock(g_mu);
+    PoolLock pl(ctx);
     int dev;
     int rc = select_device(device, &dev);
     if (rc) return rc;
     const size_t bytes = (size_t)h * w * 3;
     void *d_a, *d_b, *d_o;
-    if ((rc = slot_get(S_IMG, bytes, dev, &d_a))) return rc;
-    if ((rc = slot_get(S_AUX, bytes, dev, &d_b))) return rc;
-    if ((rc = slot_get(S_OUT, bytes, dev, &d_o))) return rc;
+    if ((rc = slot_get(pl.pool, S_IMG, bytes, dev, &d_a))) return rc;
+    if ((rc = slot_get(pl.pool, S_AUX, bytes, dev, &d_b))) return rc;
+    if ((rc = slot_get(pl.pool, S_OUT, bytes, dev, &d_o))) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(d_a, img1, bytes, hipMemcpyHostToDevice, nullptr));
     APAP_HIP_TRY(hipMemcpyAsync(d_b, img2, bytes, hipMemcpyHostToDevice, nullptr));
-    rc = apap_blend_device((const uint8_t *)d_a, (const uint8_t *)d_b, h, w, (uint8_t *)d_o, nullptr);
+    rc = apap_blend_device(ctx, (const uint8_t *)d_a, (const uint8_t *)d_b, h, w, (uint8_t *)d_o, nullptr);
     if (rc) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(out, d_o, bytes, hipMemcpyDeviceToHost, nullptr));
     APAP_HIP_TRY(hipStreamSynchronize(nullptr));
     return APAP_OK;
 }
 
-int apap_equalize_hist(const uint8_t *img, int h, int w, int channels, uint8_t *out, int device) {
+int apap_equalize_hist(apap_ctx *ctx, const uint8_t *img, int h, int w, int channels, uint8_t *out, int device) {
     if (!img || !out || h < 1 || w < 1 || channels < 1 || channels > 4)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_equalize_hist: bad argument");
-    std::lock_guard<std::mutex> lock(g_mu);
+    PoolLock pl(ctx);
     int dev;
     int rc = select_device(device, &dev);
     if (rc) return rc;
     const size_t bytes = (size_t)h * w * channels;
     const size_t work_bytes = apap_equalize_workspace_bytes(channels);
     void *d_a, *d_o, *d_work;
-    if ((rc = slot_get(S_IMG, bytes, dev, &d_a))) return rc;
-    if ((rc = slot_get(S_OUT, bytes, dev, &d_o))) return rc;
-    if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
+    if ((rc = slot_get(pl.pool, S_IMG, bytes, dev, &d_a))) return rc;
+    if ((rc = slot_get(pl.pool, S_OUT, bytes, dev, &d_o))) return rc;
+    if ((rc = slot_get(pl.pool, S_WORK, work_bytes, dev, &d_work))) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(d_a, img, bytes, hipMemcpyHostToDevice, nullptr));
     APAP_HIP_TRY(hipMemsetAsync(d_work, 0, work_bytes, nullptr));  // the pooled buffer is shared: zero it per call
-    rc = apap_equalize_hist_device((const uint8_t *)d_a, h, w, channels, (uint8_t *)d_o, d_work, work_bytes, nullptr);
+    rc = apap_equalize_hist_device(ctx, (const uint8_t *)d_a, h, w, channels, (uint8_t *)d_o, d_work, work_bytes, nullptr);
     if (rc) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(out, d_o, bytes, hipMemcpyDeviceToHost, nullptr));
     APAP_HIP_TRY(hipStreamSynchronize(nullptr));
     return APAP_OK;
 }
 
-int apap_find_homography_ransac(const float *src, const float *dst, int n, double thresh, int iterations,
+int apap_find_homography_ransac(apap_ctx *ctx, const float *src, const float *dst, int n, double thresh, int iterations,
                                 unsigned long long seed, double *H_out, uint8_t *mask_out, int *inliers_out,
                                 int device) {
     if (!src || !dst || !H_out || !mask_out || !inliers_out)
@@ -331,22 +356,22 @@ int apap_find_homography_ransac(const float *src, const float *dst, int n, doubl
     if (n < 4) return apap::fail(APAP_ERR_INVALID_ARG, "apap_find_homography_ransac: n=%d, a homography needs 4 points", n);
     int result[2] = {0, 0};
     {
-        std::lock_guard<std::mutex> lock(g_mu);
+        PoolLock pl(ctx);
         int dev;
         int rc = select_device(device, &dev);
         if (rc) return rc;
         const size_t pt_bytes = (size_t)n * 2 * sizeof(float);
         const size_t work_bytes = apap_ransac_workspace_bytes(n, iterations);
         void *d_src, *d_dst, *d_work, *d_H, *d_mask, *d_result;
-        if ((rc = slot_get(S_IMG, pt_bytes, dev, &d_src))) return rc;
-        if ((rc = slot_get(S_AUX, pt_bytes, dev, &d_dst))) return rc;
-        if ((rc = slot_get(S_WORK, work_bytes, dev, &d_work))) return rc;
-        if ((rc = slot_get(S_DENORM, 9 * sizeof(double), dev, &d_H))) return rc;
-        if ((rc = slot_get(S_OUT, (size_t)n, dev, &d_mask))) return rc;
-        if ((rc = slot_get(S_STATUS, 2 * sizeof(int), dev, &d_result))) return rc;
+        if ((rc = slot_get(pl.pool, S_IMG, pt_bytes, dev, &d_src))) return rc;
+        if ((rc = slot_get(pl.pool, S_AUX, pt_bytes, dev, &d_dst))) return rc;
+        if ((rc = slot_get(pl.pool, S_WORK, work_bytes, dev, &d_work))) return rc;
+        if ((rc = slot_get(pl.pool, S_DENORM, 9 * sizeof(double), dev, &d_H))) return rc;
+        if ((rc = slot_get(pl.pool, S_OUT, (size_t)n, dev, &d_mask))) return rc;
+        if ((rc = slot_get(pl.pool, S_STATUS, 2 * sizeof(int), dev, &d_result))) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(d_src, src, pt_bytes, hipMemcpyHostToDevice, nullptr));
         APAP_HIP_TRY(hipMemcpyAsync(d_dst, dst, pt_bytes, hipMemcpyHostToDevice, nullptr));
-        rc = apap_ransac_device((const float *)d_src, (const float *)d_dst, n, thresh, iterations, seed, (double *)d_H,
+        rc = apap_ransac_device(ctx, (const float *)d_src, (const float *)d_dst, n, thresh, iterations, seed, (double *)d_H,
                                 (uint8_t *)d_mask, (int *)d_result, d_work, work_bytes, nullptr);
         if (rc) return rc;
         APAP_HIP_TRY(hipMemcpyAsync(mask_out, d_mask, (size_t)n, hipMemcpyDeviceToHost, nullptr));
@@ -369,7 +394,7 @@ int apap_find_homography_ransac(const float *src, const float *dst, int n, doubl
     }
     const double vertex[2] = {0.0, 0.0};
     float H32[9];
-    const int rc = apap_local_homography(s_in.data(), d_in.data(), (int)(s_in.size() / 2), vertex, 1, 1, 1.0, 1.0, H32,
+    const int rc = apap_local_homography(ctx, s_in.data(), d_in.data(), (int)(s_in.size() / 2), vertex, 1, 1, 1.0, 1.0, H32,
                                          nullptr, device);
     if (rc) return rc;
     for (int i = 0; i < 9; ++i) H_out[i] = (double)H32[i];

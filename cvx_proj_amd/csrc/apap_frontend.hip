@@ -284,18 +284,18 @@ __global__ __launch_bounds__(kEqThreads) void k_eq_apply(const uint8_t *__restri
 }
 
 template <int C>
-int launch_equalize(const uint8_t *d_img, size_t bytes, int total, uint8_t *d_out, unsigned char *work, hipStream_t s) {
+int launch_equalize(apap_ctx *ctx, const uint8_t *d_img, size_t bytes, int total, uint8_t *d_out, unsigned char *work, hipStream_t s) {
     // 4 blocks per CU when the image is large: enough loads in flight, few enough blocks that
     // the per-block histogram flush stays small next to the streaming
     const size_t chunks = bytes / (kEqChunkVecs * 16) + 1;
     const unsigned blocks = (unsigned)min((size_t)1024, (chunks + kEqWaves - 1) / kEqWaves);
     {
-        apap::ProfScope prof(APAP_PROF_EQ_HIST, s);
+        apap::ProfScope prof(ctx, APAP_PROF_EQ_HIST, s);
         hipLaunchKernelGGL(k_eq_hist<C>, dim3(blocks), dim3(kEqThreads), 0, s, d_img, bytes, work);
         hipLaunchKernelGGL(k_eq_lut<C>, dim3(1), dim3(kEqThreads), 0, s, total, work);
     }
     {
-        apap::ProfScope prof(APAP_PROF_EQ_APPLY, s);
+        apap::ProfScope prof(ctx, APAP_PROF_EQ_APPLY, s);
         hipLaunchKernelGGL(k_eq_apply<C>, dim3(blocks), dim3(kEqThreads), 0, s, d_img, bytes, (const unsigned char *)work,
                            d_out);
     }
@@ -475,7 +475,7 @@ size_t apap_ransac_workspace_bytes(int n, int iterations) {
     return (size_t)iterations * 9 * sizeof(double) + (size_t)iterations * sizeof(int);
 }
 
-int apap_ransac_device(const float *d_src, const float *d_dst, int n, double thresh, int iterations,
+int apap_ransac_device(apap_ctx *ctx, const float *d_src, const float *d_dst, int n, double thresh, int iterations,
                        unsigned long long seed, double *d_H_best, uint8_t *d_mask, int *d_result, void *d_work,
                        size_t work_bytes, void *stream) {
     if (!d_src || !d_dst || !d_H_best || !d_mask || !d_result || !d_work)
@@ -493,7 +493,7 @@ int apap_ransac_device(const float *d_src, const float *d_dst, int n, double thr
     int *counts = (int *)(H + (size_t)iterations * 9);
     const double thr2 = thresh * thresh;
     {
-        apap::ProfScope prof(APAP_PROF_RANSAC, s);
+        apap::ProfScope prof(ctx, APAP_PROF_RANSAC, s);
         hipLaunchKernelGGL(k_ransac_hyp, dim3((iterations + kHypLanes - 1) / kHypLanes), dim3(kHypLanes), 0, s, d_src,
                            d_dst, n, iterations, seed, H);
         hipLaunchKernelGGL(k_ransac_score, dim3(iterations), dim3(256), 0, s, d_src, d_dst, n, (const double *)H, thr2,
@@ -511,7 +511,7 @@ size_t apap_equalize_workspace_bytes(int channels) {
     return eq_workspace(channels);
 }
 
-int apap_equalize_hist_device(const uint8_t *d_img, int h, int w, int channels, uint8_t *d_out, void *d_work,
+int apap_equalize_hist_device(apap_ctx *ctx, const uint8_t *d_img, int h, int w, int channels, uint8_t *d_out, void *d_work,
                               size_t work_bytes, void *stream) {
     if (!d_img || !d_out || !d_work) return apap::fail(APAP_ERR_INVALID_ARG, "apap_equalize_hist_device: null device pointer");
     if (h < 1 || w < 1 || channels < 1 || channels > kEqMaxChannels)
@@ -528,10 +528,10 @@ int apap_equalize_hist_device(const uint8_t *d_img, int h, int w, int channels, 
     unsigned char *hist = (unsigned char *)d_work;
     hipStream_t s = (hipStream_t)stream;
     switch (channels) {
-        case 1: return launch_equalize<1>(d_img, bytes, total, d_out, hist, s);
-        case 2: return launch_equalize<2>(d_img, bytes, total, d_out, hist, s);
-        case 3: return launch_equalize<3>(d_img, bytes, total, d_out, hist, s);
-        default: return launch_equalize<4>(d_img, bytes, total, d_out, hist, s);
+        case 1: return launch_equalize<1>(ctx, d_img, bytes, total, d_out, hist, s);
+        case 2: return launch_equalize<2>(ctx, d_img, bytes, total, d_out, hist, s);
+        case 3: return launch_equalize<3>(ctx, d_img, bytes, total, d_out, hist, s);
+        default: return launch_equalize<4>(ctx, d_img, bytes, total, d_out, hist, s);
     }
 }
 

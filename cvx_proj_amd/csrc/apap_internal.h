@@ -3,9 +3,40 @@
 #include <cstddef>
 #include <cstdint>
 
+#include <mutex>
+#include <vector>
+
 #include "../../include/apap_hip.h"
 
 namespace apap {
+
+struct ProfSpan {   // one bracketed kernel: two HIP events on the launch stream
+    int slot;
+    void *a, *b;
+};
+
+struct DevSlot {    // one pooled device buffer of the host-buffer entry points
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+};
+enum { S_TABLE, S_VERT, S_DENORM, S_H, S_WORK, S_W, S_IMG, S_OUT, S_MESHW, S_MESHH, S_HINV, S_STATUS, S_AUX, S_COUNT };
+
+}  // namespace apap
+
+// The context of include/apap_hip.h: options, profiling events, device-buffer pool.  Nothing else
+// in the library is mutable after load.
+struct apap_ctx {
+    int opt[APAP_OPT_COUNT] = {APAP_VARIANT_AUTO, APAP_EIGEN_AUTO, 1, 0, 4096, 4, 1 << 20};
+    std::vector<apap::ProfSpan> spans;
+    apap::DevSlot slots[apap::S_COUNT];
+    std::mutex mu;   // serialises the host-buffer entry points that share this context's pool
+};
+
+namespace apap {
+
+// Option `which` of `ctx`, or its built-in default when ctx is NULL.
+int opt(const apap_ctx *ctx, int which);
 
 // Records a thread-local message for apap_last_error() and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -13,15 +44,16 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // Records "<what>: <hipGetErrorString>" and returns APAP_ERR_HIP.
 int hip_fail(int hip_error, const char *what);
 
-// Optional per-kernel timing (apap_profile_enable / apap_profile_read): brackets the kernels
-// launched in its scope with HIP events on `stream`.
+// Optional per-kernel timing (APAP_OPT_PROFILE / apap_ctx_profile_read): brackets the kernels
+// launched in its scope with HIP events on `stream`, kept in the context.
 struct ProfScope {
-    ProfScope(int slot, void *stream);
+    ProfScope(apap_ctx *ctx, int slot, void *stream);
     ~ProfScope();
     ProfScope(const ProfScope &) = delete;
     ProfScope &operator=(const ProfScope &) = delete;
 
   private:
+    apap_ctx *ctx_;
     void *stream_, *a_, *b_;
     int slot_;
     bool on_;
@@ -39,7 +71,7 @@ struct SolvePlan {
     int pts_per_split; // keypoints per slice (a multiple of 4)
     size_t moment_bytes;
 };
-SolvePlan plan_solve(int n, int cells, int variant, int batch = 1);
+SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves);
 
 constexpr int kMoments = 30;       // distinct sums of A^T W^2 A
 constexpr int kStatusSingular = 1; // bit 0 of the device status word

@@ -1128,9 +1128,10 @@ __device__ __forceinline__ bool inv3(const double *m, double *out) {
 
 // per-cell inverse for the warp (apap.py:201-203): padded float32 copy for the warp
 // kernel, optional dense copy for the caller (the reference's mutated argument).
-__global__ __launch_bounds__(256) void k_invert_cells(const float *__restrict__ H, int cells,
+template <typename T>   // T = float: the reference's float32 grid; double: a float64 grid stays float64 (apap.py:201-203)
+__global__ __launch_bounds__(256) void k_invert_cells(const T *__restrict__ H, int cells,
                                                       double *__restrict__ hinv_pad,
-                                                      float *__restrict__ hinv_dense, int *status) {
+                                                      T *__restrict__ hinv_dense, int *status) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= cells) return;
     double m[9], r[9];
@@ -1139,11 +1140,11 @@ __global__ __launch_bounds__(256) void k_invert_cells(const float *__restrict__ 
     if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
     double *p = hinv_pad + (size_t)cell * APAP_HINV_STRIDE;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) p[k] = (double)(float)r[k];  // the float32 inverse, widened once
+    for (int k = 0; k < 9; ++k) p[k] = (double)(T)r[k];  // the inverse in the grid's own dtype, widened once
     p[9] = 0.0;
     if (hinv_dense) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (float)r[k];
+        for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
     }
 }
 
@@ -1182,9 +1183,10 @@ __global__ __launch_bounds__(256) void k_cell_lut(const double *__restrict__ mes
 // search per index.  Valid for any edge order, like the reference's np.where scan.
 constexpr int kMaxEdges = 4096;  // per axis; larger meshes take the linear-scan kernel
 
-__global__ __launch_bounds__(256) void k_warp_setup(const float *__restrict__ H, int cells,
+template <typename T>
+__global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int cells,
                                                     double *__restrict__ hinv_pad,
-                                                    float *__restrict__ hinv_dense, int inv_blocks,
+                                                    T *__restrict__ hinv_dense, int inv_blocks,
                                                     const double *__restrict__ mesh_w, int n_w,
                                                     const double *__restrict__ mesh_h, int n_h,
                                                     int mesh_rows, int mesh_cols, int final_w, int final_h,
@@ -1199,16 +1201,16 @@ __global__ __launch_bounds__(256) void k_warp_setup(const float *__restrict__ H,
         for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
         if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
         double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
-        // the float32 inverse (what the reference stores, apap.py:203), widened once here
-        // instead of nine v_cvt_f64_f32 per pixel in the warp kernel
-        p[0] = make_double2((double)(float)r[0], (double)(float)r[1]);
-        p[1] = make_double2((double)(float)r[2], (double)(float)r[3]);
-        p[2] = make_double2((double)(float)r[4], (double)(float)r[5]);
-        p[3] = make_double2((double)(float)r[6], (double)(float)r[7]);
-        p[4] = make_double2((double)(float)r[8], 0.0);
+        // the inverse rounded to the grid's dtype (what the reference stores back, apap.py:203),
+        // widened once here instead of nine v_cvt_f64_f32 per pixel in the warp kernel
+        p[0] = make_double2((double)(T)r[0], (double)(T)r[1]);
+        p[1] = make_double2((double)(T)r[2], (double)(T)r[3]);
+        p[2] = make_double2((double)(T)r[4], (double)(T)r[5]);
+        p[3] = make_double2((double)(T)r[6], (double)(T)r[7]);
+        p[4] = make_double2((double)(T)r[8], 0.0);
         if (hinv_dense) {
 #pragma unroll
-            for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (float)r[k];
+            for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
         }
         return;
     }
@@ -1630,18 +1632,6 @@ __global__ __launch_bounds__(256) void k_blend(const uint8_t *__restrict__ a, co
 inline int hip_fail(hipError_t e, const char *what) { return apap::hip_fail((int)e, what); }
 using apap::ProfScope;
 
-int g_variant = APAP_VARIANT_AUTO;
-int g_eigen = APAP_EIGEN_AUTO;
-int g_careful = 1;
-
-// ---- optional per-kernel timing with HIP events on the launch stream ----
-struct ProfSpan {
-    int slot;
-    hipEvent_t a, b;
-};
-bool g_prof_on = false;
-std::vector<ProfSpan> g_prof;
-
 }  // namespace
 
 namespace apap {
@@ -1650,7 +1640,13 @@ int hip_fail(int hip_error, const char *what) {
     return fail(APAP_ERR_HIP, "%s: %s", what, hipGetErrorString((hipError_t)hip_error));
 }
 
-ProfScope::ProfScope(int slot, void *stream) : stream_(stream), a_(nullptr), b_(nullptr), slot_(slot), on_(g_prof_on) {
+int opt(const apap_ctx *ctx, int which) {
+    static const apap_ctx defaults;      // never written
+    return (ctx ? ctx : &defaults)->opt[which];
+}
+
+ProfScope::ProfScope(apap_ctx *ctx, int slot, void *stream)
+    : ctx_(ctx), stream_(stream), a_(nullptr), b_(nullptr), slot_(slot), on_(ctx && ctx->opt[APAP_OPT_PROFILE]) {
     if (!on_) return;
     hipEvent_t a, b;
     on_ = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
@@ -1663,10 +1659,10 @@ ProfScope::ProfScope(int slot, void *stream) : stream_(stream), a_(nullptr), b_(
 ProfScope::~ProfScope() {
     if (!on_) return;
     (void)hipEventRecord((hipEvent_t)b_, (hipStream_t)stream_);
-    g_prof.push_back(ProfSpan{slot_, (hipEvent_t)a_, (hipEvent_t)b_});
+    ctx_->spans.push_back(ProfSpan{slot_, a_, b_});
 }
 
-SolvePlan plan_solve(int n, int cells, int variant, int batch) {
+SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves) {
     SolvePlan p{};
     if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_MFMA;  // measured faster on C2-C4, DESIGN.md
     p.variant = variant;
@@ -1678,11 +1674,7 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch) {
     // the slabs in a fixed order.  A split is at least one LDS chunk of keypoints and a whole
     // number of chunks (a partial chunk costs as much as a full one in the MFMA kernel).
     int splits = 1;
-    static const int want_waves = [] {
-        const char *e = getenv("APAP_WANT_WAVES");  // tuning knob for tools/sweep.py
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 4096;
-    }();
+    if (want_waves < 1) want_waves = 4096;
     // waves per (64-cell tile, split): the MFMA kernels' block is 4 waves on one tile (two tiles for
     // APAP_VARIANT_MFMA4X2), the VALU kernel's is 4 waves on 4 tiles
     const int waves_per_2tiles = variant == APAP_VARIANT_MFMA || variant == APAP_VARIANT_MFMA4 ? 8
@@ -1700,33 +1692,79 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch) {
 
 extern "C" {
 
-int apap_set_solver_variant(int variant) {
-    const int prev = g_variant;
-    if (variant >= APAP_VARIANT_AUTO && variant <= APAP_VARIANT_MFMA4X2) g_variant = variant;
-    return prev;
+apap_ctx *apap_ctx_create(void) { return new (std::nothrow) apap_ctx; }
+
+void apap_ctx_destroy(apap_ctx *ctx) {
+    if (!ctx) return;
+    for (apap::ProfSpan &sp : ctx->spans) {
+        (void)hipEventDestroy((hipEvent_t)sp.a);
+        (void)hipEventDestroy((hipEvent_t)sp.b);
+    }
+    for (apap::DevSlot &sl : ctx->slots)
+        if (sl.ptr) (void)hipFree(sl.ptr);
+    delete ctx;
 }
 
-int apap_set_eigen_solver(int which) {
-    const int prev = g_eigen;
-    if (which == APAP_EIGEN_AUTO || which == APAP_EIGEN_JACOBI || which == APAP_EIGEN_INVERSE_ITERATION) g_eigen = which;
-    return prev;
+int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
+    if (!ctx) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: null context (NULL means the defaults and cannot be changed)");
+    bool ok = false;
+    switch (option) {
+        case APAP_OPT_SOLVER_VARIANT: ok = value >= APAP_VARIANT_AUTO && value <= APAP_VARIANT_MFMA4X2; break;
+        case APAP_OPT_EIGEN_SOLVER: ok = value >= APAP_EIGEN_AUTO && value <= APAP_EIGEN_INVERSE_ITERATION; break;
+        case APAP_OPT_CAREFUL:
+        case APAP_OPT_PROFILE: ok = value == 0 || value == 1; break;
+        case APAP_OPT_WANT_WAVES: ok = value >= 1; break;
+        case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 2 || value == 4 || value == 8; break;
+        case APAP_OPT_WEIGHT_CHUNK_KB: ok = value >= 1; break;
+        default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
+    }
+    if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
+    ctx->opt[option] = value;
+    return APAP_OK;
 }
 
-size_t apap_solve_batch_workspace_bytes(int n, int cells, int batch) {
+int apap_ctx_get_option(const apap_ctx *ctx, int option, int *value) {
+    if (!value || option < 0 || option >= APAP_OPT_COUNT) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_get_option: bad argument");
+    *value = apap::opt(ctx, option);
+    return APAP_OK;
+}
+
+int apap_ctx_profile_read(apap_ctx *ctx, float *ms, int *launches) {
+    if (!ctx || !ms || !launches) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_profile_read: null argument");
+    for (int k = 0; k < APAP_PROF_SLOTS; ++k) {
+        ms[k] = 0.0f;
+        launches[k] = 0;
+    }
+    int rc = APAP_OK;
+    for (apap::ProfSpan &sp : ctx->spans) {
+        float t = 0.0f;
+        hipError_t e = hipEventSynchronize((hipEvent_t)sp.b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, (hipEvent_t)sp.a, (hipEvent_t)sp.b);
+        if (e != hipSuccess) rc = hip_fail(e, "apap_ctx_profile_read");
+        ms[sp.slot] += t;
+        launches[sp.slot] += 1;
+        (void)hipEventDestroy((hipEvent_t)sp.a);
+        (void)hipEventDestroy((hipEvent_t)sp.b);
+    }
+    ctx->spans.clear();
+    return rc;
+}
+
+size_t apap_solve_batch_workspace_bytes(apap_ctx *ctx, int n, int cells, int batch) {
     if (n < 1 || cells < 1 || batch < 1) return 0;
-    return apap::plan_solve(n, cells, g_variant, batch).moment_bytes * (size_t)batch;
+    return apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES)).moment_bytes * (size_t)batch;
 }
 
-size_t apap_solve_workspace_bytes(int n, int cells) { return apap_solve_batch_workspace_bytes(n, cells, 1); }
+size_t apap_solve_workspace_bytes(apap_ctx *ctx, int n, int cells) { return apap_solve_batch_workspace_bytes(ctx, n, cells, 1); }
 
-int apap_solve_batch_device(const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
                             int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
                             int batch, void *d_work, size_t work_bytes, void *stream) {
     if (!d_tables || !d_vertices || !d_denorms || !d_H || !d_work)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: null device pointer");
     if (n < 1 || cells < 1 || batch < 1 || batch > 65535 || vertices_stride < 0)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: n=%d cells=%d batch=%d", n, cells, batch);
-    const apap::SolvePlan p = apap::plan_solve(n, cells, g_variant, batch);
+    const apap::SolvePlan p = apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES));
     if (work_bytes < p.moment_bytes * (size_t)batch)
         return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes,
                           p.moment_bytes * (size_t)batch);
@@ -1742,7 +1780,7 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
     bs.denorm = APAP_DENORM_DOUBLES;
     bs.H = (long long)cells * 9;
     {
-        ProfScope prof(APAP_PROF_ASSEMBLE, s);
+        ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);
         const dim3 grid(p.cell_tiles, p.splits, batch);
         // 4 waves (64 cells) per block measured best: 2 -> 224 us, 4 -> 201 us, 8 -> 227 us at C3
         if (p.variant == APAP_VARIANT_MFMA)
@@ -1759,11 +1797,11 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
                                d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
     }
     const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
-    const int careful = g_careful;
+    const int careful = apap::opt(ctx, APAP_OPT_CAREFUL);
     {
-        ProfScope prof(APAP_PROF_EIGEN, s);
+        ProfScope prof(ctx, APAP_PROF_EIGEN, s);
         const dim3 grid(p.cell_tiles, 1, batch);
-        if (g_eigen == APAP_EIGEN_JACOBI)
+        if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)
             hipLaunchKernelGGL(k_eigen_denorm<false>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
                                pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful);
         else
@@ -1775,14 +1813,14 @@ int apap_solve_batch_device(const double *d_tables, int n, const double *d_verti
     return APAP_OK;
 }
 
-int apap_solve_device(const double *d_table, int n, const double *d_vertices, int cells,
+int apap_solve_device(apap_ctx *ctx, const double *d_table, int n, const double *d_vertices, int cells,
                       double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
                       size_t work_bytes, void *stream) {
-    return apap_solve_batch_device(d_table, n, d_vertices, 0, cells, gamma, sigma, d_denorm, d_H, 1, d_work, work_bytes,
+    return apap_solve_batch_device(ctx, d_table, n, d_vertices, 0, cells, gamma, sigma, d_denorm, d_H, 1, d_work, work_bytes,
                                    stream);
 }
 
-int apap_weights_device(const double *d_table, int n, const double *d_vertices, int cells,
+int apap_weights_device(apap_ctx *ctx, const double *d_table, int n, const double *d_vertices, int cells,
                         double gamma, double sigma, double *d_W, void *stream) {
     if (!d_table || !d_vertices || !d_W) return apap::fail(APAP_ERR_INVALID_ARG, "apap_weights_device: null device pointer");
     if (n < 1 || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_weights_device: n=%d cells=%d", n, cells);
@@ -1802,9 +1840,12 @@ size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int 
     return ((hinv + 255) / 256) * 256 + ((lut + 255) / 256) * 256;
 }
 
-static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
+}  // extern "C"
+
+template <typename T>
+static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
                          int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
-                         float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
+                         T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                          hipStream_t s, double **hinv_pad, int **lut) {
     if (!d_Hfwd || !d_mesh_w || !d_mesh_h || !d_work || !d_status)
         return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
@@ -1818,20 +1859,20 @@ static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, cons
     *lut = (int *)((char *)d_work + hinv_bytes);
     if (n_w <= kMaxEdges && n_h <= kMaxEdges) {
         // one launch: cell inverses + lookup table (reported under the INVERT slot)
-        ProfScope prof(APAP_PROF_INVERT, s);
+        ProfScope prof(ctx, APAP_PROF_INVERT, s);
         const int inv_blocks = (cells + 255) / 256;
         const int lut_blocks = (final_h + 1023) / 1024 + (final_w + 1023) / 1024;
-        hipLaunchKernelGGL(k_warp_setup, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+        hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
                            d_Hinv_out, inv_blocks, d_mesh_w, n_w, d_mesh_h, n_h, mesh_rows, mesh_cols, final_w,
                            final_h, *lut, d_status);
     } else {
         {
-            ProfScope prof(APAP_PROF_INVERT, s);
-            hipLaunchKernelGGL(k_invert_cells, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+            ProfScope prof(ctx, APAP_PROF_INVERT, s);
+            hipLaunchKernelGGL(k_invert_cells<T>, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
                                d_Hinv_out, d_status);
         }
         {
-            ProfScope prof(APAP_PROF_LUT, s);
+            ProfScope prof(ctx, APAP_PROF_LUT, s);
             hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
                                d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
         }
@@ -1839,11 +1880,12 @@ static int warp_prologue(const float *d_Hfwd, int mesh_rows, int mesh_cols, cons
     return APAP_OK;
 }
 
-static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
-                     int center_w, const float *d_Hfwd, int mesh_rows,
+template <typename T>
+static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
+                     int center_w, const T *d_Hfwd, int mesh_rows,
                      int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
-                     float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
+                     T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream, int row_begin, int row_count) {
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
     if (row_begin < 0 || row_count < 0 || (long long)row_begin + row_count > final_h)
@@ -1870,21 +1912,21 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
     hipStream_t s = (hipStream_t)stream;
     double *hinv_pad;
     int *lut;
-    const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                 d_Hinv_out, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
+    const int rc = warp_prologue<T>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
+                                    d_Hinv_out, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
     if (rc != APAP_OK) return rc;
     if (row_count == 0) return APAP_OK;  // an empty band: only the set-up kernel ran
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
-    // APAP_WARP_KERNEL (experiments): 0 = flat-order kernel, 2 / 4 / 8 = row strips of that many
+    // APAP_OPT_WARP_ROWS (experiments): 0 = flat-order kernel, 2 / 4 / 8 = row strips of that many
     // rows per wave.  Default 4: 3 / 4 / 5 / 6 measured within 2 % of each other at C3, 2 and 8 are
     // 8-10 % slower.
-    static const int warp_kernel = getenv("APAP_WARP_KERNEL") ? atoi(getenv("APAP_WARP_KERNEL")) : 4;
+    const int warp_kernel = apap::opt(ctx, APAP_OPT_WARP_ROWS);
     // the strip kernel forms source offsets with 24-bit multiplies
     // ... and marks pixels outside the source with the sign bit of the byte offset
     if (warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24) &&
         (unsigned long long)img_h * (unsigned long long)img_w * 3ull < (1ull << 31)) {
-        ProfScope prof(APAP_PROF_WARP, s);
+        ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;  // rows per wave: instantiated for 2, 4, 8
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
 #define APAP_LAUNCH_ROWS(R)                                                                                          \
@@ -1901,7 +1943,7 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
         else { APAP_LAUNCH_ROWS(2); }
 #undef APAP_LAUNCH_ROWS
     } else {
-        ProfScope prof(APAP_PROF_WARP, s);
+        ProfScope prof(ctx, APAP_PROF_WARP, s);
         const dim3 grid((unsigned)((threads + 255) / 256));
         if (d_center)
             hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
@@ -1915,36 +1957,47 @@ static int warp_impl(const uint8_t *d_img, int img_h, int img_w, const uint8_t *
     return APAP_OK;
 }
 
-int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+extern "C" {
+
+int apap_warp_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
                      int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream) {
-    return warp_impl(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
+    return warp_impl<float>(ctx, d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
                      final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream, 0, final_h);
 }
 
-int apap_warp_rows_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+int apap_warp_f64_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const double *d_Hfwd, int mesh_rows,
+                         int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
+                         int final_h, int off_x, int off_y, uint8_t *d_out, double *d_Hinv_out, void *d_work,
+                         size_t work_bytes, int *d_status, void *stream) {
+    return warp_impl<double>(ctx, d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h,
+                             n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream, 0,
+                             final_h);
+}
+
+int apap_warp_rows_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
                           int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h,
                           int final_w, int final_h, int off_x, int off_y, int row_begin, int row_count,
                           uint8_t *d_out_band, void *d_work, size_t work_bytes, int *d_status, void *stream) {
-    return warp_impl(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
+    return warp_impl<float>(ctx, d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
                      final_w, final_h, off_x, off_y, d_out_band, nullptr, d_work, work_bytes, d_status, stream, row_begin,
                      row_count);
 }
 
-int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
+int apap_stitch_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
                        int center_w, const float *d_Hfwd, int mesh_rows, int mesh_cols,
                        const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
                        int final_h, int off_x, int off_y, uint8_t *d_out, float *d_Hinv_out, void *d_work,
                        size_t work_bytes, int *d_status, void *stream) {
     if (!d_center) return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: null centre image");
-    return warp_impl(d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
+    return warp_impl<float>(ctx, d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
                      d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status,
                      stream, 0, final_h);
 }
 
-int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
+int apap_warp_coords_device(apap_ctx *ctx, const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
                             int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
                             int off_x, int off_y, double *d_coords, void *d_work, size_t work_bytes,
                             int *d_status, void *stream) {
@@ -1952,8 +2005,8 @@ int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, c
     hipStream_t s = (hipStream_t)stream;
     double *hinv_pad;
     int *lut;
-    const int rc = warp_prologue(d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                 nullptr, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
+    const int rc = warp_prologue<float>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
+                                        nullptr, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
     if (rc != APAP_OK) return rc;
     const size_t total = (size_t)final_w * final_h;
     hipLaunchKernelGGL(k_warp_coords, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hinv_pad, mesh_cols,
@@ -1963,34 +2016,7 @@ int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, c
     return APAP_OK;
 }
 
-int apap_profile_enable(int on) {
-    const int prev = g_prof_on ? 1 : 0;
-    g_prof_on = on != 0;
-    return prev;
-}
-
-int apap_profile_read(float *ms, int *launches) {
-    if (!ms || !launches) return apap::fail(APAP_ERR_INVALID_ARG, "apap_profile_read: null argument");
-    for (int k = 0; k < APAP_PROF_SLOTS; ++k) {
-        ms[k] = 0.0f;
-        launches[k] = 0;
-    }
-    int rc = APAP_OK;
-    for (ProfSpan &sp : g_prof) {
-        float t = 0.0f;
-        hipError_t e = hipEventSynchronize(sp.b);
-        if (e == hipSuccess) e = hipEventElapsedTime(&t, sp.a, sp.b);
-        if (e != hipSuccess) rc = hip_fail(e, "apap_profile_read");
-        ms[sp.slot] += t;
-        launches[sp.slot] += 1;
-        (void)hipEventDestroy(sp.a);
-        (void)hipEventDestroy(sp.b);
-    }
-    g_prof.clear();
-    return rc;
-}
-
-int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_status, void *stream) {
+int apap_flatten_device(apap_ctx *ctx, const float *d_H, int cells, double *d_out, int *d_status, void *stream) {
     if (!d_H || !d_out || !d_status) return apap::fail(APAP_ERR_INVALID_ARG, "apap_flatten_device: null device pointer");
     if (cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_flatten_device: cells=%d", cells);
     hipLaunchKernelGGL(k_flatten, dim3((cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_H, cells, d_out,
@@ -2000,7 +2026,7 @@ int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_statu
     return APAP_OK;
 }
 
-int apap_blend_device(const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream) {
+int apap_blend_device(apap_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream) {
     if (!d_a || !d_b || !d_out || h < 1 || w < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_blend_device: bad argument");
     const size_t pixels = (size_t)h * w;
     const int blocks = (int)((pixels + 255) / 256 < 16384 ? (pixels + 255) / 256 : 16384);

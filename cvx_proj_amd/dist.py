@@ -37,7 +37,7 @@ def row_partition(rows, world):
     return out
 
 
-def hip_solve(table, denorm, vertices, gamma, sigma):
+def hip_solve(table, denorm, vertices, gamma, sigma, ctx=None):
     """Default ``solve_fn``: resident-data C-ABI call on the tensors' device."""
     if not table.is_cuda:
         raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_solve needs CUDA/HIP tensors; there is no CPU fallback")
@@ -46,16 +46,16 @@ def hip_solve(table, denorm, vertices, gamma, sigma):
     H = torch.empty((cells, 9), dtype=torch.float32, device=table.device)
     if cells == 0:
         return H
-    nbytes = max(_native.lib().apap_solve_workspace_bytes(n, cells), 256)
+    nbytes = max(_native.lib().apap_solve_workspace_bytes(_native._h(ctx), n, cells), 256)
     work = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
     stream = torch.cuda.current_stream(table.device).cuda_stream
-    _native.check(_native.lib().apap_solve_device(table.data_ptr(), n, vertices.data_ptr(), cells, float(gamma),
+    _native.check(_native.lib().apap_solve_device(_native._h(ctx), table.data_ptr(), n, vertices.data_ptr(), cells, float(gamma),
                                                   float(sigma), denorm.data_ptr(), H.data_ptr(), work.data_ptr(),
                                                   nbytes, ctypes.c_void_p(stream)))
     return H
 
 
-def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_begin, row_count, out_band, shape):
+def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_begin, row_count, out_band, shape, ctx=None):
     """Default ``warp_fn``: resident-data C-ABI call warping canvas rows
     ``[row_begin, row_begin + row_count)`` into ``out_band``."""
     if not img.is_cuda:
@@ -66,13 +66,13 @@ def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_be
     status = torch.zeros(1, dtype=torch.int32, device=img.device)
     stream = torch.cuda.current_stream(img.device).cuda_stream
     _native.check(_native.lib().apap_warp_rows_device(
-        img.data_ptr(), img.shape[0], img.shape[1], H.data_ptr(), rows, cols, mesh_w.data_ptr(), mesh_w.numel(),
+        _native._h(ctx), img.data_ptr(), img.shape[0], img.shape[1], H.data_ptr(), rows, cols, mesh_w.data_ptr(), mesh_w.numel(),
         mesh_h.data_ptr(), mesh_h.numel(), final_w, final_h, off_x, off_y, row_begin, row_count, out_band.data_ptr(),
         work.data_ptr(), nbytes, status.data_ptr(), ctypes.c_void_p(stream)))
     return status
 
 
-def hip_solve_batch(tables, denorms, vertices, gamma, sigma):
+def hip_solve_batch(tables, denorms, vertices, gamma, sigma, ctx=None):
     """Several pairs (equal keypoint and cell counts, one shared mesh) in ONE launch:
     ``tables`` (B, n, 32), ``denorms`` (B, 36), ``vertices`` (cells, 2) -> H (B, cells, 9)."""
     if not tables.is_cuda:
@@ -80,10 +80,10 @@ def hip_solve_batch(tables, denorms, vertices, gamma, sigma):
     batch, n = tables.shape[0], tables.shape[1]
     cells = vertices.shape[0]
     H = torch.empty((batch, cells, 9), dtype=torch.float32, device=tables.device)
-    nbytes = max(_native.lib().apap_solve_batch_workspace_bytes(n, cells, batch), 256)
+    nbytes = max(_native.lib().apap_solve_batch_workspace_bytes(_native._h(ctx), n, cells, batch), 256)
     work = torch.empty(nbytes, dtype=torch.uint8, device=tables.device)
     stream = torch.cuda.current_stream(tables.device).cuda_stream
-    _native.check(_native.lib().apap_solve_batch_device(tables.data_ptr(), n, vertices.data_ptr(), 0, cells,
+    _native.check(_native.lib().apap_solve_batch_device(_native._h(ctx), tables.data_ptr(), n, vertices.data_ptr(), 0, cells,
                                                         float(gamma), float(sigma), denorms.data_ptr(), H.data_ptr(),
                                                         batch, work.data_ptr(), nbytes, ctypes.c_void_p(stream)))
     return H
@@ -99,8 +99,10 @@ class ShardedSolver:
     warp needs for its own rows, and what rank 0 writes).
     """
 
-    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows):
+    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows, ctx=None):
         self.pair, self.dev, self.dist, self.solve_fn, self.warp_fn = pair, dev, dist, solve_fn, warp_fn
+        # a _native.Context (options, profiling) handed to the default HIP compute functions
+        self._kw = {"ctx": ctx} if ctx is not None else {}
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.rows, self.cols = pair.vertices.shape[:2]
@@ -140,7 +142,7 @@ class ShardedSolver:
         if not self._inputs_sent:
             self.broadcast_inputs()
         a, b = self.my_rows
-        mine = self.solve_fn(self.table, self.denorm, self.vert, self.pair.gamma, self.pair.sigma)
+        mine = self.solve_fn(self.table, self.denorm, self.vert, self.pair.gamma, self.pair.sigma, **self._kw)
         if d is None or self.world == 1:
             self.H.copy_(mine)
             return self.H
@@ -183,7 +185,7 @@ class ShardedSolver:
         a, b = self.bands[self.rank]
         single = d is None or self.world == 1
         st = self.warp_fn(self.img, self.H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
-                          self.out if single else self._band, (self.rows, self.cols))     # one rank: straight into the canvas
+                          self.out if single else self._band, (self.rows, self.cols), **self._kw)   # one rank: straight into the canvas
         if st is not None:
             self.status = st
         if single:

@@ -22,6 +22,8 @@
  *    torch tensor's data_ptr()) and a hipStream_t passed as void* (NULL = the
  *    default stream).  They only enqueue work; the caller synchronises.  They are
  *    what bench.py and the multi-GPU driver use to keep data resident in HBM.
+ *  - Every compute entry point takes an apap_ctx* first (NULL = defaults): options, profiling
+ *    and the device-buffer pool live there, not in the process (section "context" below).
  *  - There is no CPU fallback.  Without a usable gfx950 device every compute entry
  *    point fails with APAP_ERR_NO_DEVICE.
  */
@@ -50,24 +52,24 @@ extern "C" {
 /* Doubles per cell in the padded inverse-homography buffer the warp kernel reads. */
 #define APAP_HINV_STRIDE 10
 
-/* Solver variants (apap_set_solver_variant).  Both produce the same numbers up to
- * the summation order of the 30 moment sums. */
+/* Solver variants (APAP_OPT_SOLVER_VARIANT).  All produce the same float32 grids on the golden
+ * vectors; they differ in the summation order of the 30 moment sums. */
 #define APAP_VARIANT_AUTO 0
 #define APAP_VARIANT_VALU 1 /* one lane per cell, fp64 FMA accumulation            */
 #define APAP_VARIANT_MFMA 2 /* v_mfma_f64_16x16x4_f64 accumulation, table via LDS  */
 #define APAP_VARIANT_MFMA4 3   /* v_mfma_f64_4x4x4_4b_f64, 16 cells per wave          */
 #define APAP_VARIANT_MFMA4X2 4 /* v_mfma_f64_4x4x4_4b_f64, 32 cells per wave share B  */
 
-/* Eigen-solvers of K2 (apap_set_eigen_solver). */
+/* Eigen-solvers of K2 (APAP_OPT_EIGEN_SOLVER). */
 #define APAP_EIGEN_AUTO 0              /* = inverse iteration with Jacobi fallback          */
 #define APAP_EIGEN_JACOBI 1            /* cyclic Jacobi sweeps only                         */
 #define APAP_EIGEN_INVERSE_ITERATION 2 /* LDL^T inverse iteration; Jacobi for cells without a
-                                          spectral gap, rank-deficient systems and n < 5     */
+                                          spectral gap and rank-deficient systems            */
 
-/* Kernel slots of apap_profile_read. */
+/* Kernel slots of apap_ctx_profile_read. */
 #define APAP_PROF_ASSEMBLE 0 /* K1: weighted moment sums A^T W^2 A      */
-#define APAP_PROF_EIGEN 1    /* K2: Jacobi eigen-solve + de-normalise   */
-#define APAP_PROF_INVERT 2   /* per-cell 3x3 inverse                    */
+#define APAP_PROF_EIGEN 1    /* K2: eigen-solve + de-normalise          */
+#define APAP_PROF_INVERT 2   /* per-cell 3x3 inverse (+ lookup table)   */
 #define APAP_PROF_LUT 3      /* canvas row/column -> cell lookup table  */
 #define APAP_PROF_WARP 4     /* K3: backward warp gather                */
 #define APAP_PROF_EQ_HIST 5  /* E1: per-channel histogram               */
@@ -80,17 +82,33 @@ const char *apap_last_error(void);
 const char *apap_version(void);
 /* Number of visible HIP devices; 0 when there is none (never an error). */
 int apap_device_count(void);
-/* Select the assembly kernel; returns the previous value.  Process-wide. */
-int apap_set_solver_variant(int variant);
-/* Select the 9x9 eigen-solver; returns the previous value.  Process-wide. */
-int apap_set_eigen_solver(int which);
 
-/* Per-kernel timing.  While enabled, the "_device" entry points bracket every kernel
- * with HIP events recorded on the launch stream.  apap_profile_read waits for them and
- * returns, per slot, the summed milliseconds and the number of launches since the
- * previous read.  Not thread-safe; meant for bench.py. */
-int apap_profile_enable(int on);
-int apap_profile_read(float *ms, int *launches);
+/* -------------------------------------------------------------------- context --- */
+/* The library keeps NO process-wide mutable state (the reference's class is re-entrant: all of
+ * its state is on `self`, apap.py:22-32).  Every compute entry point takes an `apap_ctx *` as its
+ * first argument; NULL means "the built-in defaults, no profiling" and is always valid.  A context
+ * carries the options below, the HIP events of its profiling, and the pool of device buffers its
+ * host-buffer calls reuse.  One context must not be used from two threads at once; different
+ * contexts (and NULL) are independent - NULL-context host-buffer calls share one pool and are
+ * serialised on it. */
+typedef struct apap_ctx apap_ctx;
+#define APAP_OPT_SOLVER_VARIANT 0 /* APAP_VARIANT_*; default AUTO (= MFMA)                              */
+#define APAP_OPT_EIGEN_SOLVER 1   /* APAP_EIGEN_*; default AUTO                                         */
+#define APAP_OPT_CAREFUL 2        /* 1 (default): cells whose eigen-gap is below 1e-4 of the trace, and every
+                                     cell when n < 5, are re-solved from the weighted 2n x 9 rows (Givens QR +
+                                     one-sided Jacobi) as apap.py:159-161 does; 0: normal equations only    */
+#define APAP_OPT_PROFILE 3        /* 1: bracket every kernel with HIP events (apap_ctx_profile_read)     */
+#define APAP_OPT_WANT_WAVES 4     /* tuning: waves K1 aims at before it stops splitting the keypoints     */
+#define APAP_OPT_WARP_ROWS 5      /* tuning: canvas rows per wave of K3 (2, 4, 8; 0 = flat-order kernel)  */
+#define APAP_OPT_WEIGHT_CHUNK_KB 6 /* device staging of the optional weight tensor, KiB (default 1 GiB)   */
+#define APAP_OPT_COUNT 7
+apap_ctx *apap_ctx_create(void);
+void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
+int apap_ctx_set_option(apap_ctx *ctx, int option, int value);
+int apap_ctx_get_option(const apap_ctx *ctx, int option, int *value); /* ctx may be NULL: the defaults */
+/* Waits for the events recorded since the previous read and returns, per slot, the summed
+ * milliseconds and the number of launches. */
+int apap_ctx_profile_read(apap_ctx *ctx, float *ms, int *launches);
 
 /* ------------------------------------------------------------ host-only helpers --- */
 /* No GPU needed.  They restate, in C and in float32 exactly as numpy evaluates the
@@ -128,7 +146,7 @@ int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, 
  *   W_out      NULL, or mesh_rows x mesh_cols x n float64 (the reference's second
  *              return value; 8*n bytes per cell of extra HBM + PCIe traffic)
  *   device     HIP device index, or -1 for the current device */
-int apap_local_homography(const float *src, const float *dst, int n, const double *vertices,
+int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int n, const double *vertices,
                           int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
                           double *W_out, int device);
 
@@ -140,17 +158,26 @@ int apap_local_homography(const float *src, const float *dst, int n, const doubl
  *   out        final_h x final_w x 3 uint8
  *   Hinv_out   NULL, or mesh_rows x mesh_cols x 9 float32 receiving the inverses (what
  *              the reference leaves in its mutated argument) */
-int apap_local_warp(const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
+int apap_local_warp(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const float *Hfwd, int mesh_rows,
                     int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
                     int final_w, int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out,
                     int device);
+
+/* APAP.local_warp for a float64 grid.  The reference inverts the cells in the grid's own dtype
+ * (apap.py:201-203: numpy.linalg.inv keeps float64) and multiplies in float64, so a float64 grid is
+ * NOT rounded to float32 on the way: Hfwd and Hinv_out are float64 here, everything else is as
+ * apap_local_warp. */
+int apap_local_warp_f64(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const double *Hfwd, int mesh_rows,
+                        int mesh_cols, const double *mesh_w, int n_w, const double *mesh_h, int n_h,
+                        int final_w, int final_h, int off_x, int off_y, uint8_t *out, double *Hinv_out,
+                        int device);
 
 /* The stitch the reference's __main__ keeps commented out (apap.py:258-262), fused into
  * one pass: warp `img` like apap_local_warp, paste `center` (center_h x center_w x 3) at
  * (off_x, off_y) on an empty canvas, uniform_blend (apap_utils.py:75-88) the two.  The
  * centre image must fit the canvas at the offsets (the reference's slice assignment raises
  * otherwise): APAP_ERR_INVALID_ARG. */
-int apap_local_stitch(const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
+int apap_local_stitch(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
                       int center_w, const float *Hfwd, int mesh_rows, int mesh_cols,
                       const double *mesh_w, int n_w, const double *mesh_h, int n_h, int final_w,
                       int final_h, int off_x, int off_y, uint8_t *out, float *Hinv_out, int device);
@@ -158,30 +185,30 @@ int apap_local_stitch(const uint8_t *img, int img_h, int img_w, const uint8_t *c
 /* Same inputs as apap_local_warp; writes the float64 target coordinates (tx, ty) of
  * every canvas pixel (apap.py:211-213) instead of gathering.  coords: final_h x
  * final_w x 2 float64.  For parity tests of the coordinate arithmetic. */
-int apap_warp_coords(const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
+int apap_warp_coords(apap_ctx *ctx, const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w, int n_w,
                      const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
                      double *coords, int device);
 
 /* Output stage of apap.py:250-264: per cell H <- inv(H), H /= H[2,2] (float32), then
  * the transposed 3x3 flattened to 9 float64.  H: cells x 9 float32; out: cells x 9. */
-int apap_invert_normalize_flatten(const float *H, int cells, double *out, int device);
+int apap_invert_normalize_flatten(apap_ctx *ctx, const float *H, int cells, double *out, int device);
 
 /* uniform_blend (apap_utils.py:75-88) over two h x w x 3 uint8 canvases. */
-int apap_uniform_blend(const uint8_t *img1, const uint8_t *img2, int h, int w, uint8_t *out,
+int apap_uniform_blend(apap_ctx *ctx, const uint8_t *img1, const uint8_t *img2, int h, int w, uint8_t *out,
                        int device);
 
 /* -------------------------------------------------- resident (device) entry points --- */
 
 /* Bytes of scratch apap_solve_device needs for this problem size. */
-size_t apap_solve_workspace_bytes(int n, int cells);
+size_t apap_solve_workspace_bytes(apap_ctx *ctx, int n, int cells);
 
 /* Per-cell weighted DLT + eigen-solve + de-normalisation on resident data.
  *   d_table    n x APAP_TABLE_STRIDE doubles   (apap_host_build_table)
  *   d_vertices cells x 2 doubles
  *   d_denorm   APAP_DENORM_DOUBLES doubles     (apap_host_build_denorm)
  *   d_H        cells x 9 floats (output)
- *   d_work     scratch of apap_solve_workspace_bytes(n, cells) bytes */
-int apap_solve_device(const double *d_table, int n, const double *d_vertices, int cells,
+ *   d_work     scratch of apap_solve_workspace_bytes(ctx, n, cells) bytes */
+int apap_solve_device(apap_ctx *ctx, const double *d_table, int n, const double *d_vertices, int cells,
                       double gamma, double sigma, const double *d_denorm, float *d_H, void *d_work,
                       size_t work_bytes, void *stream);
 
@@ -189,13 +216,13 @@ int apap_solve_device(const double *d_table, int n, const double *d_vertices, in
  * (blockIdx.z = pair): d_tables batch x n x 32, d_denorms batch x 36, d_H batch x cells x 9;
  * d_vertices + k * vertices_stride is pair k's mesh (stride in doubles; 0 = one mesh shared
  * by all pairs).  Fills the chip with fewer keypoint splits than `batch` separate calls. */
-size_t apap_solve_batch_workspace_bytes(int n, int cells, int batch);
-int apap_solve_batch_device(const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+size_t apap_solve_batch_workspace_bytes(apap_ctx *ctx, int n, int cells, int batch);
+int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
                             int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
                             int batch, void *d_work, size_t work_bytes, void *stream);
 
 /* The weights tensor alone: d_W cells x n doubles. */
-int apap_weights_device(const double *d_table, int n, const double *d_vertices, int cells,
+int apap_weights_device(apap_ctx *ctx, const double *d_table, int n, const double *d_vertices, int cells,
                         double gamma, double sigma, double *d_W, void *stream);
 
 size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h);
@@ -203,36 +230,42 @@ size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int 
 /* Backward warp on resident data.  d_status: one int the kernels OR error bits into
  * (bit 0: singular cell, bit 1: index error); zero it before the call.  d_Hinv_out
  * may be NULL. */
-int apap_warp_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+int apap_warp_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
                      int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream);
 
+/* apap_warp_device for a float64 grid (see apap_local_warp_f64). */
+int apap_warp_f64_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const double *d_Hfwd, int mesh_rows,
+                         int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
+                         int final_h, int off_x, int off_y, uint8_t *d_out, double *d_Hinv_out, void *d_work,
+                         size_t work_bytes, int *d_status, void *stream);
+
 /* apap_warp_device restricted to canvas rows [row_begin, row_begin + row_count): what one
  * rank computes when the warp of ONE pair is sharded over GPUs (cvx_proj_amd/dist.py).
  * d_out_band receives row_count x final_w x 3 bytes. */
-int apap_warp_rows_device(const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
+int apap_warp_rows_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
                           int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h,
                           int final_w, int final_h, int off_x, int off_y, int row_begin, int row_count,
                           uint8_t *d_out_band, void *d_work, size_t work_bytes, int *d_status, void *stream);
 
 /* Resident-data twin of apap_local_stitch. */
-int apap_stitch_device(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
+int apap_stitch_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
                        int center_w, const float *d_Hfwd, int mesh_rows, int mesh_cols,
                        const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
                        int final_h, int off_x, int off_y, uint8_t *d_out, float *d_Hinv_out, void *d_work,
                        size_t work_bytes, int *d_status, void *stream);
 
 /* Coordinates-only twin of apap_warp_device (d_coords: final_h x final_w x 2 doubles). */
-int apap_warp_coords_device(const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
+int apap_warp_coords_device(apap_ctx *ctx, const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
                             int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
                             int off_x, int off_y, double *d_coords, void *d_work, size_t work_bytes,
                             int *d_status, void *stream);
 
-int apap_flatten_device(const float *d_H, int cells, double *d_out, int *d_status, void *stream);
+int apap_flatten_device(apap_ctx *ctx, const float *d_H, int cells, double *d_out, int *d_status, void *stream);
 
-int apap_blend_device(const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream);
+int apap_blend_device(apap_ctx *ctx, const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint8_t *d_out, void *stream);
 
 /* ------------------------------------------- callers of the path --- */
 /* Pre-processing of apap.py:236-237 = utils.py:85-91 visualize_equalized_hist:
@@ -240,13 +273,13 @@ int apap_blend_device(const uint8_t *d_a, const uint8_t *d_b, int h, int w, uint
  * on an interleaved uint8 image of 1..4 channels (h x w x channels); out may alias nothing.
  * cv::equalizeHist (opencv-python 4.6.0.66, absent from this image) is restated from its
  * published algorithm: see oracle/frontend_oracle.py. */
-int apap_equalize_hist(const uint8_t *img, int h, int w, int channels, uint8_t *out, int device);
+int apap_equalize_hist(apap_ctx *ctx, const uint8_t *img, int h, int w, int channels, uint8_t *out, int device);
 size_t apap_equalize_workspace_bytes(int channels);
 /* Resident-data form: three kernels on `stream` (histogram; table; mapping).  WORKSPACE
  * CONTRACT: d_work (16-byte aligned, apap_equalize_workspace_bytes(channels) bytes) must be all
  * zero on entry - zero it once after allocating it - and is all zero again, apart from the table
  * at its end, when the call's kernels have run; so back-to-back calls need no memset. */
-int apap_equalize_hist_device(const uint8_t *d_img, int h, int w, int channels, uint8_t *d_out, void *d_work,
+int apap_equalize_hist_device(apap_ctx *ctx, const uint8_t *d_img, int h, int w, int channels, uint8_t *d_out, void *d_work,
                               size_t work_bytes, void *stream);
 
 /* Seed homography, the contract of baseline_stitch_test.py:42
@@ -260,13 +293,13 @@ int apap_equalize_hist_device(const uint8_t *d_img, int h, int w, int channels, 
  * oracle/frontend_oracle.py is its specification. */
 #define APAP_RANSAC_ITERATIONS 2048
 #define APAP_RANSAC_SEED 0x5EEDC0DE5EEDC0DEull
-int apap_find_homography_ransac(const float *src, const float *dst, int n, double thresh, int iterations,
+int apap_find_homography_ransac(apap_ctx *ctx, const float *src, const float *dst, int n, double thresh, int iterations,
                                 unsigned long long seed, double *H_out, uint8_t *mask_out, int *inliers_out,
                                 int device);
 size_t apap_ransac_workspace_bytes(int n, int iterations);
 /* Device half (no re-fit): d_H_best 9 doubles = the winning 4-point model, d_mask n bytes,
  * d_result 2 ints = {winning hypothesis, its inlier count}.  Points 8-byte aligned. */
-int apap_ransac_device(const float *d_src, const float *d_dst, int n, double thresh, int iterations,
+int apap_ransac_device(apap_ctx *ctx, const float *d_src, const float *d_dst, int n, double thresh, int iterations,
                        unsigned long long seed, double *d_H_best, uint8_t *d_mask, int *d_result, void *d_work,
                        size_t work_bytes, void *stream);
 

@@ -36,6 +36,56 @@ def test_version_and_constants(native):
         assert int(re.search(rf"#define APAP_{name} (\d+)", text).group(1)) == val == getattr(native, name)
 
 
+def test_contexts_hold_the_options_not_the_process(native):
+    """No process-wide switches: two contexts carry different options side by side, NULL means the
+    immutable defaults, invalid values are refused, and nothing of it needs a GPU."""
+    a = native.Context(variant=native.VARIANT_VALU, eigen=native.EIGEN_JACOBI)
+    b = native.Context()
+    assert (a.get("variant"), a.get("eigen"), a.get("careful")) == (native.VARIANT_VALU, native.EIGEN_JACOBI, 1)
+    assert (b.get("variant"), b.get("eigen"), b.get("careful"), b.get("warp_rows")) == (native.VARIANT_AUTO, native.EIGEN_AUTO, 1, 4)
+    v = ctypes.c_int(-1)
+    assert native.lib().apap_ctx_get_option(None, native.OPT_WANT_WAVES, ctypes.byref(v)) == native.OK and v.value == 4096
+    assert native.lib().apap_ctx_set_option(None, native.OPT_CAREFUL, 0) == native.ERR_INVALID_ARG      # NULL cannot be changed
+    for name, bad in (("variant", 9), ("eigen", -1), ("careful", 2), ("warp_rows", 3), ("want_waves", 0)):
+        with pytest.raises(ValueError):
+            b.set(name, bad)
+    # the workspace a solve needs follows the context's variant, not a global
+    n, cells = 2000, 40000
+    ws_default = native.lib().apap_solve_workspace_bytes(None, n, cells)
+    ws_valu = native.lib().apap_solve_workspace_bytes(native._h(a), n, cells)
+    assert ws_default > 0 and ws_valu > 0 and ws_valu != ws_default
+    assert native.lib().apap_solve_workspace_bytes(native._h(b), n, cells) == ws_default
+    prof = a.profile_read()
+    assert set(prof) == set(native.PROF_NAMES) and all(v == (0.0, 0) for v in prof.values())
+    import threading
+    seen = {}
+
+    def worker(k):      # contexts created and used on other threads are independent objects
+        c = native.Context(want_waves=1000 + k)
+        seen[k] = c.get("want_waves")
+        c.close()
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert seen == {k: 1000 + k for k in range(4)} and b.get("want_waves") == 4096
+    a.close()
+    b.close()
+    native.lib().apap_ctx_destroy(None)     # a no-op
+
+
+def test_no_process_wide_state_in_the_library_sources():
+    """The product's native sources keep no mutable globals for options or profiling and read no
+    environment variable (knobs are context options)."""
+    csrc = os.path.join(ROOT, "cvx_proj_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            assert "getenv" not in text, f
+            assert not re.search(r"^\s*(static\s+)?(int|bool)\s+g_\w+\s*=", text, flags=re.M), f
+
+
 def test_no_cpu_fallback(native):
     """Without a device every compute entry point must refuse, not compute on the host."""
     if native.lib().apap_device_count() > 0:

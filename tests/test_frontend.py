@@ -203,17 +203,17 @@ def test_equalize_device_entry_any_alignment(native):
         buf_in = torch.zeros(nbytes + 32, dtype=torch.uint8, device=dev)
         buf_out = torch.zeros(nbytes + 32, dtype=torch.uint8, device=dev)
         buf_in[off_in:off_in + nbytes] = torch.from_numpy(img.ravel()).to(dev)
-        native.check(native.lib().apap_equalize_hist_device(buf_in.data_ptr() + off_in, h, w, c,
+        native.check(native.lib().apap_equalize_hist_device(None, buf_in.data_ptr() + off_in, h, w, c,
                                                             buf_out.data_ptr() + off_out, work.data_ptr(),
                                                             work.numel(), ctypes.c_void_p(0)))
         torch.cuda.synchronize()
         got = buf_out[off_out:off_out + nbytes].cpu().numpy().reshape(h, w, c)
         assert np.array_equal(got, ref), (off_in, off_out)
         assert int(buf_out[:off_out].sum()) == 0 and int(buf_out[off_out + nbytes:].sum()) == 0   # nothing outside
-    rc = native.lib().apap_equalize_hist_device(buf_in.data_ptr(), h, w, 5, buf_out.data_ptr(), work.data_ptr(),
+    rc = native.lib().apap_equalize_hist_device(None, buf_in.data_ptr(), h, w, 5, buf_out.data_ptr(), work.data_ptr(),
                                                 work.numel(), ctypes.c_void_p(0))
     assert rc == native.ERR_INVALID_ARG
-    rc = native.lib().apap_equalize_hist_device(buf_in.data_ptr(), h, w, c, buf_out.data_ptr(), work.data_ptr(),
+    rc = native.lib().apap_equalize_hist_device(None, buf_in.data_ptr(), h, w, c, buf_out.data_ptr(), work.data_ptr(),
                                                 8, ctypes.c_void_p(0))
     assert rc == native.ERR_WORKSPACE
 
@@ -296,7 +296,7 @@ def test_ransac_device_half_is_bit_identical_to_the_oracle(native, n, outliers, 
     Hb = torch.zeros(9, dtype=torch.float64, device=dev)
     mask = torch.zeros(n, dtype=torch.uint8, device=dev)
     res = torch.zeros(2, dtype=torch.int32, device=dev)
-    native.check(native.lib().apap_ransac_device(d_src.data_ptr(), d_dst.data_ptr(), n, 5.0, K, ctypes.c_ulonglong(F.RANSAC_SEED),
+    native.check(native.lib().apap_ransac_device(None, d_src.data_ptr(), d_dst.data_ptr(), n, 5.0, K, ctypes.c_ulonglong(F.RANSAC_SEED),
                                                  Hb.data_ptr(), mask.data_ptr(), res.data_ptr(), work.data_ptr(), wb,
                                                  ctypes.c_void_p(0)))
     torch.cuda.synchronize()

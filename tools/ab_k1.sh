@@ -4,7 +4,7 @@
 CFG=${1:-C3}
 for r in $(seq ${ROUNDS:-3}); do
   for V in mfma mfma4 mfma4x2 valu; do
-    python bench.py --config $CFG --steps 30 --no-cpu-baseline --variant $V 2>/dev/null | python -c "
+    python bench.py --config $CFG --steps 30 --no-cpu-baseline --no-cells --no-call-level --variant $V 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernels_ms']
 print('$CFG %-8s H/s=%.3e  assemble=%.1f us eigen=%.1f us solve step %.1f us' % ('$V', d['value'], k['assemble']*1e3, k['eigen']*1e3, d['solve_ms_per_step']*1e3))"
