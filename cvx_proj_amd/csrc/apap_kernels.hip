@@ -792,6 +792,7 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
 // gamma = 0 and sigma of a few pixels the weights span 10+ orders of magnitude and it falls to
 // 1e-7 ... 1e-20 (soak seeds 544, 659, 795, 814, 883: hundreds of pixels off).  A cell whose gap is
 // below kGapTol * trace is re-solved from the weighted rows themselves (qr_resolve below).
+constexpr int kFusedMaxCells = 4096;  // meshes up to this many cells (x batch) take the fused K1 + K2 launch
 constexpr double kGapTol = 1e-4;  // normal-equation error ~ 50 eps / kGapTol = 1e-10 relative at the threshold
 
 __device__ __forceinline__ double rcp_fast(double x) {  // ~2^-46: only signs of pivots are used
@@ -973,30 +974,13 @@ __device__ __forceinline__ void qr_resolve(const double *__restrict__ table, int
     }
 }
 
-// K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
+// The per-cell tail shared by K2 and the fused small-mesh kernel: from the 30 moment sums of a
+// cell to its float32 homography.  Lanes = cells; inactive lanes are simply not in the wave votes.
 template <bool kUseInverseIteration>
-__global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
-                                                     int cells, int cells_pad,
-                                                     const double *__restrict__ denorm, int pick_rank,
-                                                     float *__restrict__ H, BatchStride bs,
-                                                     const double *__restrict__ table, int n,
-                                                     const double *__restrict__ vertices, double gamma,
-                                                     double inv_sigma, int careful) {
-    moments += (long long)blockIdx.z * bs.moments;
-    denorm += (long long)blockIdx.z * bs.denorm;
-    H += (long long)blockIdx.z * bs.H;
-    table += (long long)blockIdx.z * bs.table;
-    vertices += (long long)blockIdx.z * bs.vertices;
-    const int cell = blockIdx.x * kWave + threadIdx.x;
-    const int cc = min(cell, cells - 1);
-    double m[kMoments];
-#pragma unroll
-    for (int j = 0; j < kMoments; ++j) m[j] = moments[(size_t)j * cells_pad + cc];
-    for (int g = 1; g < splits; ++g) {  // slabs of the keypoint splits, fixed order
-        const double *slab = moments + (size_t)g * kMoments * cells_pad + cc;
-#pragma unroll
-        for (int j = 0; j < kMoments; ++j) m[j] += slab[(size_t)j * cells_pad];
-    }
+__device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], const double *__restrict__ denorm,
+                                                  int pick_rank, int careful, const double *__restrict__ table, int n,
+                                                  double vx, double vy, double gamma, double inv_sigma,
+                                                  float *__restrict__ out /* 9 floats, or nullptr */) {
     // A^T W^2 A = [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]  (3x3 blocks)
     double a[45];
 #pragma unroll
@@ -1037,7 +1021,7 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
     }
     if (__any(careful_cell)) {
         double hq[9];
-        qr_resolve(table, n, vertices[2 * cc], vertices[2 * cc + 1], inv_sigma, gamma, pick_rank, hq);
+        qr_resolve(table, n, vx, vy, inv_sigma, gamma, pick_rank, hq);
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = careful_cell ? hq[k] : h[k];
     }
@@ -1046,11 +1030,130 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
     mul3(t1, denorm + 9, t2);   // . C1
     mul3(denorm + 18, t2, t1);  // inv(N2) .
     mul3(t1, denorm + 27, t2);  // . N1
-    if (cell < cells) {
-        float *out = H + (size_t)cell * 9;
+    if (out) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) out[k] = (float)(t2[k] / t2[8]);
     }
+}
+
+// K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
+template <bool kUseInverseIteration>
+__global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
+                                                     int cells, int cells_pad,
+                                                     const double *__restrict__ denorm, int pick_rank,
+                                                     float *__restrict__ H, BatchStride bs,
+                                                     const double *__restrict__ table, int n,
+                                                     const double *__restrict__ vertices, double gamma,
+                                                     double inv_sigma, int careful) {
+    moments += (long long)blockIdx.z * bs.moments;
+    denorm += (long long)blockIdx.z * bs.denorm;
+    H += (long long)blockIdx.z * bs.H;
+    table += (long long)blockIdx.z * bs.table;
+    vertices += (long long)blockIdx.z * bs.vertices;
+    const int cell = blockIdx.x * kWave + threadIdx.x;
+    const int cc = min(cell, cells - 1);
+    double m[kMoments];
+#pragma unroll
+    for (int j = 0; j < kMoments; ++j) m[j] = moments[(size_t)j * cells_pad + cc];
+    for (int g = 1; g < splits; ++g) {  // slabs of the keypoint splits, fixed order
+        const double *slab = moments + (size_t)g * kMoments * cells_pad + cc;
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) m[j] += slab[(size_t)j * cells_pad];
+    }
+    eigen_denorm_cell<kUseInverseIteration>(m, denorm, pick_rank, careful, table, n, vertices[2 * cc], vertices[2 * cc + 1],
+                                            gamma, inv_sigma, cell < cells ? H + (size_t)cell * 9 : nullptr);
+}
+
+// --------------------------------------------------------------------------------
+// K1 + K2 fused for small meshes (a few thousand cells: config C1 is 400).  There the two-launch
+// path is bound by launch latency and by the few waves it can start, not by arithmetic.  Here a
+// block owns ONE 16-cell group; its four waves split the keypoints (wave w takes steps w, w+4,
+// w+8, w+12 of every 64-keypoint LDS chunk), add their accumulators through LDS in a fixed order,
+// and wave 0 finishes the 16 cells with the K2 tail: one launch, no moment slabs in HBM, four times
+// as many blocks as K1 would start.  Register use is the K2 tail's (one wave per SIMD): fine for the
+// few dozen to few hundred blocks this kernel is dispatched for.
+// --------------------------------------------------------------------------------
+template <bool kUseInverseIteration>
+__global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ table, int n,
+                                                     const double *__restrict__ vertices, int cells, double gamma,
+                                                     double inv_sigma, const double *__restrict__ denorm, int pick_rank,
+                                                     int careful, float *__restrict__ H, BatchStride bs) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
+    __shared__ double s_exp2[kExpN];
+    table += (long long)blockIdx.z * bs.table;
+    vertices += (long long)blockIdx.z * bs.vertices;
+    denorm += (long long)blockIdx.z * bs.denorm;
+    H += (long long)blockIdx.z * bs.H;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < kExpN; j += 256) s_exp2[j] = kExp2Tab[j];
+    const double gamma2 = gamma > 0.0 ? gamma * gamma : 0.0;
+    const double scaled_inv_sigma2 = 2.0 * inv_sigma * kExpScale;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kgrp = lane >> 4, col = lane & 15;
+    const int cell = blockIdx.x * 16 + col;
+    const int cc = min(cell, cells - 1);
+    const double vx = vertices[2 * cc], vy = vertices[2 * cc + 1];
+    const int nchunks = (n + kChunk - 1) / kChunk;
+
+    constexpr int kPieces = kChunk * 16 / 256;
+    double2 stage[kPieces];
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = tid + 256 * i;
+            const int p = c * kChunk + (q >> 4);
+            stage[i] = (p < n) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
+                               : make_double2(0.0, 0.0);
+        }
+    };
+    auto store_chunk = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < kPieces; ++i) {
+            const int q = tid + 256 * i;
+            const int r = q >> 4;
+            const int slot = (q & 15) ^ ((r & 1) << 3);
+            *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[i];
+        }
+    };
+    const int off_xy = lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col), off_b1 = lds_off(kgrp, 16 + col);
+    double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const unsigned char *buf = lds[c & 1] + 1024 * wave;
+#pragma unroll
+        for (int i = 0; i < kChunk / 16; ++i) {  // this wave's steps: wave, wave + 4, wave + 8, wave + 12
+            const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
+            const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
+            const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
+            const double w2 = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
+        }
+        if (c + 1 < nchunks) store_chunk((c + 1) & 1);
+        __syncthreads();
+    }
+    // cross-wave reduction through LDS (the chunk buffers are free now): part[wave][cell][32 moments].
+    // D layout: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15] = (cell, moment)
+    double *part = reinterpret_cast<double *>(&lds[0][0]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ci = kgrp + 4 * i;
+        part[(wave * 16 + ci) * 32 + col] = acc0[i];
+        part[(wave * 16 + ci) * 32 + 16 + col] = acc1[i];
+    }
+    __syncthreads();
+    if (wave != 0 || lane >= 16) return;       // lanes 0..15 of wave 0 = the block's 16 cells
+    double m[kMoments];
+#pragma unroll
+    for (int j = 0; j < kMoments; ++j)
+        m[j] = ((part[(0 * 16 + lane) * 32 + j] + part[(1 * 16 + lane) * 32 + j]) + part[(2 * 16 + lane) * 32 + j]) +
+               part[(3 * 16 + lane) * 32 + j];
+    eigen_denorm_cell<kUseInverseIteration>(m, denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
+                                            cell < cells ? H + (size_t)cell * 9 : nullptr);
 }
 
 // --------------------------------------------------------------------------------
@@ -1779,6 +1882,23 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
     bs.moments = (long long)(p.moment_bytes / sizeof(double));
     bs.denorm = APAP_DENORM_DOUBLES;
     bs.H = (long long)cells * 9;
+    const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
+    const int careful = apap::opt(ctx, APAP_OPT_CAREFUL);
+    // Small meshes (AUTO only): one fused launch, 16 cells per block.  Up to 4096 cells in all the
+    // blocks fit the chip in about one round at the fused kernel's one wave per SIMD.
+    if (apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO && (long long)cells * batch <= kFusedMaxCells) {
+        ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);   // reported under the K1 slot; the K2 slot stays empty
+        const dim3 grid((cells + 15) / 16, 1, batch);
+        if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)
+            hipLaunchKernelGGL(k_solve_small<false>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
+                               d_denorms, pick_rank, careful, d_H, bs);
+        else
+            hipLaunchKernelGGL(k_solve_small<true>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
+                               d_denorms, pick_rank, careful, d_H, bs);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
+        return APAP_OK;
+    }
     {
         ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);
         const dim3 grid(p.cell_tiles, p.splits, batch);
@@ -1796,8 +1916,6 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
             hipLaunchKernelGGL(k_assemble_valu, dim3((p.cell_tiles + 3) / 4, p.splits, batch), dim3(256), 0, s, d_tables, n,
                                d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
     }
-    const int pick_rank = 9 - (2 * n < 9 ? 2 * n : 9);
-    const int careful = apap::opt(ctx, APAP_OPT_CAREFUL);
     {
         ProfScope prof(ctx, APAP_PROF_EIGEN, s);
         const dim3 grid(p.cell_tiles, 1, batch);

@@ -192,11 +192,16 @@ def _denormalise(h, p):
     return h / h[2, 2]
 
 
-def local_homography_loop(src_point, dst_point, vertices, gamma, sigma, cells=None, want_weights=True):
+def local_homography_loop(src_point, dst_point, vertices, gamma, sigma, cells=None, want_weights=True, cond_out=None):
     """Faithful restatement of ``APAP.local_homography`` (apap.py:121-169): one
     weighted 2N x 9 SVD per mesh cell in float64, float32 store.  ``numpy.linalg.svd``
     stands in for ``cv.SVDecomp``.  ``cells`` optionally restricts the loop to a list
-    of (i, j) pairs (used by the bounded CPU-baseline timing); other cells stay 0."""
+    of (i, j) pairs (used by the bounded CPU-baseline timing); other cells stay 0.
+
+    ``cond_out`` (a float64 array of the mesh's shape, test diagnostics only) receives per cell
+    ``sigma_1 / (sigma_k-1 - sigma_k)`` of the weighted system, k = the index of the vector taken:
+    times the machine epsilon it is the forward error of that singular vector in ANY backward-stable
+    float64 SVD - how far the reference's own float64 result is from the exact one."""
     n = src_point.shape[0]
     rows, cols, _ = vertices.shape
     p = prepare(src_point, dst_point)
@@ -209,8 +214,11 @@ def local_homography_loop(src_point, dst_point, vertices, gamma, sigma, cells=No
         if want_weights:
             W[i, j, :] = weight
         A = np.expand_dims(np.repeat(weight, 2), -1) * aa
-        _, _, vt = np.linalg.svd(A, full_matrices=False)
+        _, sv, vt = np.linalg.svd(A, full_matrices=False)
         H[i, j] = _denormalise(vt[-1, :], p)
+        if cond_out is not None:
+            gap = (sv[-2] - sv[-1]) if len(sv) > 1 else sv[-1]
+            cond_out[i, j] = sv[0] / gap if gap > 0 else np.inf
     return H, W
 
 

@@ -21,7 +21,9 @@ script is how they were made.
                 whole grid and of its in-place inverses, the 8K warped canvas (SHA-256 + every 256th row; ~3 min more)
     C5          eight of the 64 independent pairs (pairs 0, 1 in full, 2..7 every 4th mesh row + SHA-256 of the grid)
     illcond     illcond_ref: the six soak seeds of round 1 whose weighted systems are numerically rank-deficient
-                (gamma = 0, sigma <= 10 px, 5-17 keypoints), through the reference's APAP.local_homography
+                (gamma = 0, sigma <= 10 px, 5-17 keypoints), through the reference's APAP.local_homography;
+                illcond_truth: five seeds of round 2's soak on which the reference's float64 SVD itself is lost,
+                with the exact answer of sampled cells from a 60-digit SVD of the reference's own matrix
 
 Two things the reference needs that this image lacks, and how they are served:
 * ``cv2`` (OpenCV) is not installed.  ``apap.py`` uses exactly one OpenCV function on
@@ -152,6 +154,60 @@ def illcond_cases(ref_apap, name="illcond_ref.npz"):
                                                              + c["verts"].tobytes()).digest(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, name), **out)
     print(f"{name}: seeds {ILLCOND_SEEDS}")
+
+
+ILLCOND_TRUTH_SEEDS = (1974, 5588, 5634, 5814, 6012)   # round 2's 5000-seed soak: the REFERENCE is up to 6.6 px off here
+
+
+def illcond_truth_cases(ref_apap, name="illcond_truth.npz", cells_per_seed=10 ** 9):
+    """Inputs on which the reference's own float64 SVD is lost (sigma_8 / sigma_1 down to 1e-16 with
+    gamma = 0, sigma = 3 px, 5-6 keypoints): its H grid AND, for every cell, the exact
+    answer - the same weighted 2n x 9 float64 matrix the reference builds (apap.py:150-159), its SVD
+    taken in 60-digit arithmetic (mpmath), the last right singular vector de-normalised with the
+    reference's own float32 matrices (apap.py:163-167).  Stored per seed: the reference grid, the
+    sampled cell indices, the exact float32 H of those cells, sigma_1 / (sigma_8 - sigma_9)."""
+    import mpmath as mp
+    mp.mp.dps = 60
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_fuzz import random_case
+    out = {"seeds": np.array(ILLCOND_TRUTH_SEEDS)}
+    for seed in ILLCOND_TRUTH_SEEDS:
+        c = random_case(1000 + seed)
+        fw, fh = c["canvas"]
+        eng = ref_apap.APAP(c["gamma"], c["sigma"], [fw, fh], list(c["off"]))
+        src, dst, verts = c["src"], c["dst"], c["verts"]
+        with np.errstate(all="ignore"):
+            H_ref, W_ref = eng.local_homography(src, dst, verts)
+        N1, nf1 = eng.getNormalize2DPts(src)
+        N2, nf2 = eng.getNormalize2DPts(dst)
+        C1, C2 = eng.getConditionerFromPts(nf1), eng.getConditionerFromPts(nf2)
+        aa = eng.matrix_generate(len(src), eng.point_normalize(nf1, C1), eng.point_normalize(nf2, C2))
+        rows, cols = verts.shape[:2]
+        rng = np.random.default_rng(seed)
+        flat = rng.choice(rows * cols, size=min(cells_per_seed, rows * cols), replace=False)
+        exact, cond = [], []
+        for f in flat:
+            i, j = int(f // cols), int(f % cols)
+            A = np.expand_dims(np.repeat(W_ref[i, j], 2), -1) * aa          # apap.py:159 on the reference's own weights
+            _, S, V = mp.svd_r(mp.matrix(A.tolist()), full_matrices=False, compute_uv=True)
+            sv = sorted((S[k] for k in range(len(S))), reverse=True)
+            kmin = min(range(len(S)), key=lambda k: S[k])
+            h = np.array([float(V[kmin, k]) for k in range(9)]).reshape(3, 3)
+            h = np.linalg.inv(C2).dot(h).dot(C1)
+            h = np.linalg.inv(N2).dot(h).dot(N1)
+            exact.append((h / h[2, 2]).astype(np.float32))
+            cond.append(float(sv[0] / (sv[-2] - sv[-1])))
+        out[f"H{seed}"] = H_ref
+        out[f"cells{seed}"] = flat
+        out[f"exact{seed}"] = np.stack(exact)
+        out[f"cond{seed}"] = np.array(cond)
+        out[f"src_sha{seed}"] = np.frombuffer(hashlib.sha256(src.tobytes() + dst.tobytes() + verts.tobytes()).digest(),
+                                              dtype=np.uint8)
+        d = np.abs(H_ref.reshape(-1, 9)[flat] - np.stack(exact).reshape(-1, 9)).max()
+        print(f"  seed {seed}: {len(flat)} cells, cond up to {max(cond):.1e}, reference vs exact max |dH| {d:.2e}")
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: seeds {ILLCOND_TRUTH_SEEDS}")
 
 
 def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_every=1, seed_offset=0):
@@ -351,6 +407,7 @@ def main():
         config_case(ref_apap, ref_utils, "C4", "c4_ref_rows8.npz", warp_rows_every=256, keep_rows_every=8)
     if "illcond" in which:
         illcond_cases(ref_apap)
+        illcond_truth_cases(ref_apap)
 
 
 if __name__ == "__main__":

@@ -8,6 +8,9 @@ import pytest
 from oracle import apap_oracle as O
 
 pytestmark = pytest.mark.gpu
+# forward error of a singular vector from a normwise backward-stable float64 SVD of a 2n x 9 matrix:
+# REF_SVD_ERR * eps * sigma_1 / gap (LAPACK's backward error constant is a modest multiple of eps)
+REF_SVD_ERR = 32.0
 
 
 def random_case(seed):
@@ -43,7 +46,8 @@ def random_case(seed):
 def test_fuzz_solve_and_warp(native, seed):
     c = random_case(1000 + seed)
     H, W = native.local_homography(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"])
-    H_ref, W_ref = O.local_homography_loop(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"])
+    cond = np.zeros(c["verts"].shape[:2])
+    H_ref, W_ref = O.local_homography_loop(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"], cond_out=cond)
     assert np.allclose(W, W_ref, rtol=1e-14, atol=1e-300)
     ok = np.isfinite(H_ref).all(axis=(2, 3))
     assert (np.isfinite(H).all(axis=(2, 3)) == ok).all()
@@ -53,11 +57,20 @@ def test_fuzz_solve_and_warp(native, seed):
     # from the weighted rows by K2), a relative 1e-5 to the blown-up ones.
     scale = np.abs(O.project(H_ref[ok], c["src"])).max(axis=(1, 2))
     sane = scale < 50.0 * max(c["img"].shape[:2])
+    # The reference's own float64 SVD is only determined to eps * sigma_1 / (sigma_8 - sigma_9) (its
+    # LAPACK routine is normwise backward stable, no better): with gamma = 0, sigma = 3 px and 5-6
+    # keypoints that reaches 1e-3 ... 1 and the REFERENCE is px away from the exact answer (a 5000-seed
+    # soak found 12 such inputs; on each the engine's careful path equals a 60-digit SVD after float32
+    # rounding - test_more_accurate_than_the_reference_where_it_is_lost).  Where the reference's error
+    # bound exceeds a tenth of the bar, the bar is that bound.
+    ref_err = REF_SVD_ERR * np.finfo(np.float64).eps * cond[ok] * np.maximum(scale, 1.0)
+    bar = np.maximum(1e-4, ref_err)
     print(f"seed {seed}: n={c['n']} mesh={c['shape']} max delta {d.max():.2e} px, sane cells {int(sane.sum())}/{sane.size}, "
-          f"float32 values differing {int((H[ok] != H_ref[ok]).sum())}")
-    assert (d / np.maximum(scale, 1.0)).max() < 1e-5, f"seed {seed}: {d.max()}"
+          f"float32 values differing {int((H[ok] != H_ref[ok]).sum())}, cells where the reference is not determined to "
+          f"1e-5 px: {int((ref_err > 1e-5).sum())}")
+    assert (d / np.maximum(scale, 1.0) < np.maximum(1e-5, ref_err / np.maximum(scale, 1.0))).all(), f"seed {seed}: {d.max()}"
     if sane.any():
-        assert d[sane].max() < 1e-4, f"seed {seed}: {d[sane].max()}"
+        assert (d[sane] < bar[sane]).all(), f"seed {seed}: {(d[sane] / bar[sane]).max()} x the bar, {d[sane].max()} px"
     # warp with the REFERENCE homographies (so the comparison isolates the warp)
     fw, fh = c["canvas"]
     ox, oy = c["off"]
@@ -110,6 +123,35 @@ def test_ill_conditioned_cells_vs_reference(native, golden, seed):
         Hn, _ = native.local_homography(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"], want_weights=False, ctx=fast)
         fast.close()
         assert O.reprojection_rmse_delta(Hn, H_ref, c["src"]).max() > 1e-3
+
+
+@pytest.mark.parametrize("seed", [1974, 5588, 5634, 5814, 6012])
+def test_more_accurate_than_the_reference_where_it_is_lost(native, golden, seed):
+    """Round 2's 5000-seed soak: 12 inputs (gamma = 0, sigma = 3 px, 5-6 keypoints) where engine and
+    reference disagree by up to 6.6 px.  There sigma_8 / sigma_1 of the weighted system is 1e-11 ... 1e-16
+    and the reference's float64 LAPACK SVD is itself off by that much: tests/golden/illcond_truth.npz
+    holds the reference's grid AND the exact answer of every cell (60-digit SVD of the reference's
+    own matrix, make_golden.py illcond).  The engine must match the EXACT answer at the parity bar and
+    the reference within the reference's own error bound."""
+    import hashlib
+    g = golden("illcond_truth")
+    c = random_case(1000 + seed)
+    sha = hashlib.sha256(c["src"].tobytes() + c["dst"].tobytes() + c["verts"].tobytes()).digest()
+    assert sha == g[f"src_sha{seed}"].tobytes()
+    H, _ = native.local_homography(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"], want_weights=False)
+    H_ref, cells, exact, cond = g[f"H{seed}"], g[f"cells{seed}"], g[f"exact{seed}"], g[f"cond{seed}"]
+    mine = H.reshape(-1, 3, 3)[cells]
+    d_exact = O.reprojection_rmse_delta(mine, exact, c["src"])
+    d_ref_exact = O.reprojection_rmse_delta(H_ref.reshape(-1, 3, 3)[cells], exact, c["src"])
+    print(f"seed {seed}: engine vs exact max {d_exact.max():.2e} px; reference vs exact max {d_ref_exact.max():.2e} px; "
+          f"sigma_1 / gap up to {cond.max():.1e}")
+    assert d_exact.max() < 1e-4
+    assert d_ref_exact.max() > 1e-4                 # the reference really is lost on these inputs
+    scale = np.abs(O.project(exact, c["src"])).max(axis=(1, 2))
+    bound = np.maximum(1e-4, REF_SVD_ERR * np.finfo(np.float64).eps * cond * scale)
+    assert (d_ref_exact < bound).all()              # ... by no more than its error bound: the bar of the fuzz test is sound
+    d_all = O.reprojection_rmse_delta(H, H_ref, c["src"])
+    assert np.isfinite(d_all).all()
 
 
 # ------------------------------------------------------------------ callers of the path

@@ -740,6 +740,26 @@ def test_other_warp_kernel_forms_still_match(native, golden, rows_per_wave):
     ctx.close()
 
 
+def test_source_with_a_side_of_2_to_the_24_takes_the_flat_order_kernel(native):
+    """The strip kernel forms source offsets with 24-bit multiplies; a source with a side of 2^24
+    pixels must be dispatched to the flat-order kernel (apap_kernels.hip warp_impl) - and still give
+    the reference's pixels.  A 1 x 16 777 216 image (48 MiB), a small canvas that looks at its far end."""
+    rng = np.random.default_rng(23)
+    w = 1 << 24
+    img = rng.integers(1, 256, (1, w, 3), dtype=np.uint8)
+    fw, fh = 200, 3
+    shift = float(w - 150)
+    # canvas (x, y) -> source (x + shift, y + 0.5): H maps source -> canvas
+    H = np.tile(np.array([[1, 0, -shift], [0, 1, -0.5], [0, 0, 1]], np.float32), (1, 2, 1, 1))
+    mesh_w, mesh_h = np.array([0.0, 100.0, 200.0]), np.array([0.0, 3.0])
+    out, hinv = native.local_warp(img, H, mesh_w, mesh_h, fw, fh, 0, 0)
+    hinv_ref = np.linalg.inv(H.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(hinv, hinv_ref)
+    ref = O.local_warp_fast(img, hinv_ref, (mesh_w, mesh_h), (fw, fh), (0, 0))
+    assert np.array_equal(out, ref) and out.any()
+    assert not out[:, 160:].any()          # beyond the right edge of the source: left black
+
+
 def test_float64_grid_stays_float64(native, golden):
     """The reference inverts the cells in the grid's own dtype and multiplies in float64
     (apap.py:201-203,210-213): a float64 grid is not rounded to float32.  Checked against the
