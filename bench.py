@@ -344,6 +344,7 @@ def main():
                     help="capture the solve and the warp step into HIP graphs and time graph replays")
     ap.add_argument("--want-waves", type=int, help="tuning: APAP_OPT_WANT_WAVES of the context (K1 keypoint splits)")
     ap.add_argument("--warp-rows", type=int, choices=[0, 2, 4, 8], help="tuning: APAP_OPT_WARP_ROWS (0 = flat-order warp kernel)")
+    ap.add_argument("--fused-max-cells", type=int, help="tuning: APAP_OPT_FUSED_MAX_CELLS (fused K1 + K2 launch for small meshes)")
     ap.add_argument("--cpu-cells", type=int, default=40000)
     ap.add_argument("--cpu-rows", type=int, default=400)
     ap.add_argument("--cpu-pool", type=int, default=-1,
@@ -379,6 +380,8 @@ def main():
         ctx.set("want_waves", a.want_waves)
     if a.warp_rows is not None:
         ctx.set("warp_rows", a.warp_rows)
+    if a.fused_max_cells is not None:
+        ctx.set("fused_max_cells", a.fused_max_cells)
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():

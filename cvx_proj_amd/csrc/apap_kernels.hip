@@ -792,7 +792,6 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
 // gamma = 0 and sigma of a few pixels the weights span 10+ orders of magnitude and it falls to
 // 1e-7 ... 1e-20 (soak seeds 544, 659, 795, 814, 883: hundreds of pixels off).  A cell whose gap is
 // below kGapTol * trace is re-solved from the weighted rows themselves (qr_resolve below).
-constexpr int kFusedMaxCells = 4096;  // meshes up to this many cells (x batch) take the fused K1 + K2 launch
 constexpr double kGapTol = 1e-4;  // normal-equation error ~ 50 eps / kGapTol = 1e-10 relative at the threshold
 
 __device__ __forceinline__ double rcp_fast(double x) {  // ~2^-46: only signs of pivots are used
@@ -1819,6 +1818,7 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_WANT_WAVES: ok = value >= 1; break;
         case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 2 || value == 4 || value == 8; break;
         case APAP_OPT_WEIGHT_CHUNK_KB: ok = value >= 1; break;
+        case APAP_OPT_FUSED_MAX_CELLS: ok = value >= 0; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
     }
     if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
@@ -1886,7 +1886,7 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
     const int careful = apap::opt(ctx, APAP_OPT_CAREFUL);
     // Small meshes (AUTO only): one fused launch, 16 cells per block.  Up to 4096 cells in all the
     // blocks fit the chip in about one round at the fused kernel's one wave per SIMD.
-    if (apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO && (long long)cells * batch <= kFusedMaxCells) {
+    if (apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO && (long long)cells * batch <= apap::opt(ctx, APAP_OPT_FUSED_MAX_CELLS)) {
         ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);   // reported under the K1 slot; the K2 slot stays empty
         const dim3 grid((cells + 15) / 16, 1, batch);
         if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)

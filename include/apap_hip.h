@@ -101,7 +101,9 @@ typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_WANT_WAVES 4     /* tuning: waves K1 aims at before it stops splitting the keypoints     */
 #define APAP_OPT_WARP_ROWS 5      /* tuning: canvas rows per wave of K3 (2, 4, 8; 0 = flat-order kernel)  */
 #define APAP_OPT_WEIGHT_CHUNK_KB 6 /* device staging of the optional weight tensor, KiB (default 1 GiB)   */
-#define APAP_OPT_COUNT 7
+#define APAP_OPT_FUSED_MAX_CELLS 7 /* tuning: meshes of up to this many cells (x batch) take the fused K1 + K2
+                                      launch when the variant is AUTO (default 4096; 0 = never)             */
+#define APAP_OPT_COUNT 8
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);

@@ -30,6 +30,8 @@ def main():
             except Exception as e:      # noqa: BLE001
                 bad.append((name, seed, repr(e)[:200]))
                 traceback.print_exc(limit=1)
+            if (seed - lo) % 250 == 249:      # a long silent run looks hung to the GPU box's watchdog
+                print(f"{name}: seed {seed}, failures so far {len(bad)}", flush=True)
         print(f"{name}: seeds {lo}..{hi - 1} done, failures so far {len(bad)}", flush=True)
     for b in bad:
         print("FAIL", *b)
