@@ -14,7 +14,8 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapap_hip.so")
+# APAP_HIP_LIB: load another build of the library (A/B tooling: tools/ab_build.sh); default in-tree
+LIB_PATH = os.environ.get("APAP_HIP_LIB") or os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
 # kernel slots of apap_profile_read (include/apap_hip.h)

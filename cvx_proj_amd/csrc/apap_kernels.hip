@@ -361,6 +361,9 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #ifndef APAP_K1_CHUNK
 #define APAP_K1_CHUNK 64
 #endif
+#ifndef APAP_K1_GROUP
+#define APAP_K1_GROUP 8
+#endif
 constexpr int kChunk = APAP_K1_CHUNK;
 static_assert(kChunk % 16 == 0 && kChunk % 4 == 0, "chunk must split evenly over 256 threads and 4-keypoint steps");
 
@@ -434,6 +437,31 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         if (c + 1 < nchunks) load_chunk(c + 1);
         const unsigned char *buf = lds[c & 1];
         // a partial last chunk runs all 16 steps: its missing rows are zero
+#if APAP_K1_GROUP > 1
+        // The weights of g steps first, then their 2 g MFMAs back to back: g times fewer MFMA <-> VALU
+        // transitions (~10 issue cycles each, profiles/r02_coexec.txt) and g independent weight chains
+        // for the scheduler.  Same MFMAs in the same order per accumulator: bit-identical sums.
+        // A/B at C3 on one box (tools/ab_build.sh): g = 1: 169.5-170.7 us, 2: 165.5-166.3, 4: 165.5-166.1,
+        // 8: 163.8-164.1, 16: 163.9-164.2.
+#pragma unroll
+        for (int s0 = 0; s0 < kChunk / 4; s0 += APAP_K1_GROUP) {
+            double w2[APAP_K1_GROUP];
+#pragma unroll
+            for (int g = 0; g < APAP_K1_GROUP; ++g) {
+                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * (s0 + g));
+                w2[g] = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < APAP_K1_GROUP; ++g) {
+                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * (s0 + g));
+                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * (s0 + g));
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[g], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[g], b1, acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll  // all 16 steps: LDS addresses become immediates (-3 % vs unroll 4)
         for (int s = 0; s < kChunk / 4; ++s) {
             // row 4 s + kgrp: its parity is kgrp's, so the swizzled offset is a per-lane base
@@ -445,6 +473,7 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
         }
+#endif
         if (c + 1 < nchunks) store_chunk((c + 1) & 1);
         __syncthreads();
     }
@@ -1123,15 +1152,21 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk(c + 1);
         const unsigned char *buf = lds[c & 1] + 1024 * wave;
+        double w2[kChunk / 16];  // this wave's steps: wave, wave + 4, wave + 8, wave + 12; weights first (see k_assemble_mfma)
 #pragma unroll
-        for (int i = 0; i < kChunk / 16; ++i) {  // this wave's steps: wave, wave + 4, wave + 8, wave + 12
+        for (int i = 0; i < kChunk / 16; ++i) {
             const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
+            w2[i] = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kChunk / 16; ++i) {
             const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
             const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
-            const double w2 = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b1, acc1, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < nchunks) store_chunk((c + 1) & 1);
         __syncthreads();
     }

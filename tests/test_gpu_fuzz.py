@@ -9,8 +9,10 @@ from oracle import apap_oracle as O
 
 pytestmark = pytest.mark.gpu
 # forward error of a singular vector from a normwise backward-stable float64 SVD of a 2n x 9 matrix:
-# REF_SVD_ERR * eps * sigma_1 / gap (LAPACK's backward error constant is a modest multiple of eps)
-REF_SVD_ERR = 32.0
+# REF_SVD_ERR * eps * sigma_1 / gap (LAPACK's backward error constant is a modest multiple of eps).
+# Calibrated on an 8000-seed soak (tools/long_fuzz.py 40 8000): with 32 one seed (6607) exceeded the bound by
+# a factor 1.17 in a cell where the engine equals the 60-digit answer and the reference is 2.9e-4 px off.
+REF_SVD_ERR = 128.0
 
 
 def random_case(seed):
