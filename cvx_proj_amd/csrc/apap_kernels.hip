@@ -442,7 +442,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         // transitions (~10 issue cycles each, profiles/r02_coexec.txt) and g independent weight chains
         // for the scheduler.  Same MFMAs in the same order per accumulator: bit-identical sums.
         // A/B at C3 on one box (tools/ab_build.sh): g = 1: 169.5-170.7 us, 2: 165.5-166.3, 4: 165.5-166.1,
-        // 8: 163.8-164.1, 16: 163.9-164.2.
+        // 8: 163.8-164.1, 16: 163.9-164.2.  (s_setprio 1 / 3 around the MFMA group: +-1 %; a 128-keypoint
+        // chunk: +4 %; profiles/r02_k1_variants.txt.)
 #pragma unroll
         for (int s0 = 0; s0 < kChunk / 4; s0 += APAP_K1_GROUP) {
             double w2[APAP_K1_GROUP];
