@@ -26,12 +26,13 @@ def need_gpu(native):
     assert native.lib().apap_device_count() >= 1, "these tests need a GPU; the library found none"
 
 
-@pytest.fixture(params=[(1, 1), (1, 2), (2, 1), (2, 2), (3, 2), (4, 2)],
-                ids=["valu-jacobi", "valu-invit", "mfma-jacobi", "mfma-invit", "mfma4-invit", "mfma4x2-invit"])
+@pytest.fixture(params=[(0, 0), (0, 1), (1, 1), (1, 2), (2, 1), (2, 2), (3, 2), (4, 2)],
+                ids=["auto", "auto-jacobi", "valu-jacobi", "valu-invit", "mfma-jacobi", "mfma-invit", "mfma4-invit", "mfma4x2-invit"])
 def variant(request, native):
-    """Combinations of the K1 kernel (VALU / MFMA 16x16x4 / MFMA 4x4x4 with 16 or 32 cells per wave)
-    and the K2 eigen-solver (Jacobi / inverse iteration with Jacobi fallback), as a context to pass
-    to the calls (``ctx=variant``): the library has no process-wide switches."""
+    """Combinations of the K1 kernel (AUTO = the fused K1 + K2 launch for meshes of up to 4096 cells and
+    MFMA 16x16x4 above / VALU / MFMA 16x16x4 / MFMA 4x4x4 with 16 or 32 cells per wave) and the K2
+    eigen-solver (Jacobi / inverse iteration with Jacobi fallback), as a context to pass to the calls
+    (``ctx=variant``): the library has no process-wide switches."""
     ctx = native.Context(variant=request.param[0], eigen=request.param[1])
     yield ctx
     ctx.close()
@@ -177,6 +178,49 @@ def test_device_entry_points_with_torch_memory(native, golden):
     rc = native.lib().apap_solve_device(None, d_table.data_ptr(), len(p.src), d_vert.data_ptr(), cells, p.gamma, p.sigma,
                                         d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(), 16, ctypes.c_void_p(stream))
     assert rc == native.ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("cells,n,batch", [(1, 5, 1), (15, 63, 1), (16, 64, 1), (17, 65, 3), (4096, 130, 1), (1024, 200, 4),
+                                          (4097, 130, 1), (1366, 200, 3)])
+def test_fused_small_mesh_launch_around_its_limits(native, cells, n, batch):
+    """k_solve_small (one launch, 16 cells per block, 4-wave keypoint split) takes meshes of up to 4096
+    cells x batch under APAP_VARIANT_AUTO: cell counts around a block, keypoint counts around a chunk,
+    batches, both sides of the threshold - against the two-launch MFMA path on the same device buffers
+    and against the oracle."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(cells * 7 + n)
+    dev = torch.device("cuda:0")
+    tabs, dens, srcs, dsts = [], [], [], []
+    for b in range(batch):
+        p = synth_pair(640, 480, n, 4, seed=900 + b + n)
+        q = native.host_prepare(p.src, p.dst)
+        tabs.append(native.host_build_table(p.src, q["cf1"], q["cf2"]))
+        dens.append(native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"]))
+        srcs.append(p.src)
+        dsts.append(p.dst)
+    verts = rng.random((cells, 2)) * [640, 480]
+    d_tab = torch.from_numpy(np.stack(tabs)).to(dev)
+    d_den = torch.from_numpy(np.stack(dens)).to(dev)
+    d_vert = torch.from_numpy(verts).to(dev)
+    out = {}
+    for name, ctx in (("auto", native.Context()), ("mfma", native.Context(variant=native.VARIANT_MFMA))):
+        H = torch.empty((batch, cells, 9), dtype=torch.float32, device=dev)
+        nbytes = max(native.lib().apap_solve_batch_workspace_bytes(native._h(ctx), n, cells, batch), 256)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        native.check(native.lib().apap_solve_batch_device(native._h(ctx), d_tab.data_ptr(), n, d_vert.data_ptr(), 0, cells, 0.5, 40.0,
+                                                          d_den.data_ptr(), H.data_ptr(), batch, work.data_ptr(), nbytes,
+                                                          ctypes.c_void_p(0)))
+        torch.cuda.synchronize()
+        out[name] = H.cpu().numpy()
+        ctx.close()
+    flips = int((out["auto"] != out["mfma"]).sum())
+    print(f"cells={cells} n={n} batch={batch}: float32 values differing fused vs two-launch: {flips} of {out['auto'].size}")
+    assert flips <= max(2, out["auto"].size // 100000)       # the same sums in another order
+    for b in range(batch):
+        H_ref, _ = O.local_homography_loop(srcs[b], dsts[b], verts[None, :64], 0.5, 40.0, want_weights=False)
+        d = O.reprojection_rmse_delta(out["auto"][b, :64].reshape(1, -1, 3, 3), H_ref, srcs[b])
+        assert d.max() < RMSE_BAR
 
 
 def test_solve_is_bitwise_reproducible(native, variant):
