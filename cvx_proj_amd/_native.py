@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("APAP_HIP_LIB") or os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
-# kernel slots of apap_profile_read (include/apap_hip.h)
+# kernel slots of apap_ctx_profile_read (include/apap_hip.h)
 PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply", "ransac")
 PROF_SLOTS = len(PROF_NAMES)
 TABLE_STRIDE = 32
