@@ -1027,24 +1027,28 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
         }
     a[tri(6, 6)] = m[24]; a[tri(6, 7)] = m[25]; a[tri(6, 8)] = m[26];
     a[tri(7, 7)] = m[27]; a[tri(7, 8)] = m[28]; a[tri(8, 8)] = m[29];
-    const double gap_tol = kGapTol * (2.0 * (m[0] + m[3] + m[5]) + m[24] + m[27] + m[29]);  // kGapTol * trace
+    const double trace = 2.0 * (m[0] + m[3] + m[5]) + m[24] + m[27] + m[29];
+    const double gap_tol = kGapTol * trace;
+    // The sums are of w^2: where every weight is below ~1e-140 they underflow (partly or entirely)
+    // although the weights themselves - what the reference's SVD works on - are ordinary numbers.
+    const bool underflowed = !(trace >= 1e-280) || !(trace < 1.797e308);   // also NaN / inf sums
 
     double h[9];
     bool have = false;
     // Fewer than 5 keypoints (pick_rank != 0): the reference's V[-1] is the singular vector of the
     // smallest KEPT singular value of the thin SVD, lambda_(9-2n) of a matrix with 9 - 2n exact
     // zeros below it: always the careful path.
-    bool careful_cell = careful && pick_rank != 0;
+    bool careful_cell = careful && (pick_rank != 0 || underflowed);
     if (kUseInverseIteration && pick_rank == 0) {
         double rho;
         have = inverse_iteration(a, h, rho);
         // a second eigenvalue within gap_tol of the smallest?  (rho >= lambda_9, so lambda_9 counts)
-        if (careful) careful_cell = have && count_eigs_below(m, rho + gap_tol) >= 2;
+        if (careful && !careful_cell) careful_cell = have && count_eigs_below(m, rho + gap_tol) >= 2;
     }
     if (!__all(have || careful_cell)) {  // rare: no spectral gap, pivot not positive (n < 5 with careful == 0)
         double hj[9];
         const double gap = jacobi_eigvec(a, pick_rank, hj);
-        if (careful && pick_rank == 0 && !have) careful_cell = !(gap >= gap_tol);  // also for NaN
+        if (careful && pick_rank == 0 && !have && !careful_cell) careful_cell = !(gap >= gap_tol);  // also for NaN
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = have ? h[k] : hj[k];
     }

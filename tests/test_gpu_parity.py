@@ -567,6 +567,63 @@ def test_edge_cases_vs_reference(native, golden, variant, k):
     assert d.max() < RMSE_BAR      # n = 4 (case 0) included
 
 
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_fewer_than_five_keypoints_vs_oracle(native, variant, n):
+    """2n < 9: the thin SVD keeps 2n vectors and V[-1] belongs to the smallest KEPT singular value
+    (apap.py:160-161).  K2 sends these systems to the QR / one-sided-Jacobi path (Jacobi on the normal
+    matrix when the careful path is what is being compared against): same grid as the reference's SVD."""
+    rng = np.random.default_rng(40 + n)
+    src = (rng.random((n, 2)) * [640, 480]).astype(np.float32)
+    dst = (src * 1.01 + rng.normal(0, 2.0, (n, 2)) + [5, -3]).astype(np.float32)
+    verts = np.stack(np.meshgrid(np.linspace(10, 630, 7), np.linspace(10, 470, 5)), axis=-1)
+    H, _ = native.local_homography(src, dst, verts, 0.3, 80.0, want_weights=False, ctx=variant)
+    H_ref, _ = O.local_homography_loop(src, dst, verts, 0.3, 80.0, want_weights=False)
+    ok = np.isfinite(H_ref).all(axis=(2, 3))
+    assert (np.isfinite(H).all(axis=(2, 3)) == ok).all()
+    pts = (rng.random((50, 2)) * [640, 480]).astype(np.float32)
+    d = O.reprojection_rmse_delta(H[ok], H_ref[ok], pts)
+    scale = np.maximum(np.abs(O.project(H_ref[ok], pts)).max(axis=(1, 2)), 1.0)
+    print(f"n={n}: max delta {d.max():.2e} px (relative {np.max(d / scale):.2e}), float32 values differing {int((H[ok] != H_ref[ok]).sum())}")
+    assert (d / scale).max() < 1e-6
+
+
+def test_degenerate_inputs_terminate_with_the_reference_s_finiteness(native):
+    """Collinear keypoints (the DLT system loses rank), coincident keypoints, keypoints far outside
+    the image, gamma = 0 with every weight underflowing: the kernels must terminate and be finite
+    wherever the reference is; where the reference's answer is determined, match it."""
+    rng = np.random.default_rng(77)
+    verts = np.stack(np.meshgrid(np.linspace(0, 640, 9), np.linspace(0, 480, 7)), axis=-1)
+    t = np.linspace(0, 1, 30)
+    cases = {
+        "collinear": (np.stack([100 + 400 * t, 50 + 300 * t], axis=1).astype(np.float32), None, 0.5, 60.0),
+        "coincident": (np.tile(np.array([[320.0, 240.0]], np.float32), (12, 1)), None, 0.5, 60.0),
+        "far away": ((rng.random((40, 2)) * [640, 480] + 1e6).astype(np.float32), None, 0.0, 50.0),
+        "clustered, gamma 0, sigma 2": ((rng.random((9, 2)) * 8 + [300, 200]).astype(np.float32), None, 0.0, 2.0),
+    }
+    for name, (src, dst, gamma, sigma) in cases.items():
+        dst = (src * 0.98 + [3, 4] + rng.normal(0, 0.5, src.shape)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            H_ref, _ = O.local_homography_loop(src, dst, verts, gamma, sigma, want_weights=False)
+        H, _ = native.local_homography(src, dst, verts, gamma, sigma, want_weights=False)      # returns = terminated
+        fin_ref, fin = np.isfinite(H_ref).all(axis=(2, 3)), np.isfinite(H).all(axis=(2, 3))
+        print(f"{name}: finite cells reference {int(fin_ref.sum())} / engine {int(fin.sum())} of {fin.size}")
+        assert H.shape == H_ref.shape and (fin | ~fin_ref).all()       # finite wherever the reference is
+        if name == "far away":
+            # gamma = 0 and every w = exp(-400) ~ 1e-174: w^2 underflows to 0, w does not - the reference's SVD of
+            # W A is an ordinary problem, and so is the careful path's QR of the same rows
+            assert fin_ref.all()
+            d = O.reprojection_rmse_delta(H, H_ref, src)
+            print(f"   all w^2 underflow, w = {np.exp(-400.0):.1e}: max delta vs the reference {d.max():.2e} px at coordinates of 1e6 px")
+            assert d.max() < 1.0       # float32 H at 1e6-px coordinates resolves ~0.1 px
+    # the well-posed one of them: far-away keypoints are an ordinary system after Hartley normalisation
+    src, _, gamma, sigma = cases["far away"]
+    dst = (src * 0.98 + [3, 4]).astype(np.float32)
+    H, _ = native.local_homography(src, dst, verts, 0.5, sigma, want_weights=False)
+    H_ref, _ = O.local_homography_loop(src, dst, verts, 0.5, sigma, want_weights=False)
+    d = O.reprojection_rmse_delta(H, H_ref, src)
+    assert d.max() < 1e-4 * max(1.0, np.abs(src).max() / 4000.0) * 1e3       # coordinates of 1e6 px: float32 H resolves ~0.1 px
+
+
 def test_all_weights_underflow_does_not_hang(native):
     """sigma so small that exp underflows to 0 and gamma = 0: the normal matrix is exactly
     zero; the solver must terminate (Jacobi fallback on a zero matrix) - values are whatever
