@@ -1111,7 +1111,12 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
                                                      const double *__restrict__ vertices, int cells, double gamma,
                                                      double inv_sigma, const double *__restrict__ denorm, int pick_rank,
                                                      int careful, float *__restrict__ H, BatchStride bs) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][kChunk * 256];
+    // The block is alone on its CU (the K2 tail's registers) and its waves take only 4 steps of a
+    // chunk each, far too little work to hide the next chunk's global load behind: kRing chunks are
+    // fetched per round with their loads all in flight together (C1's 150 keypoints: one round, one
+    // exposed latency), and the next round's loads fly during this round's arithmetic.
+    constexpr int kRing = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kRing][kChunk * 256];
     __shared__ double s_exp2[kExpN];
     table += (long long)blockIdx.z * bs.table;
     vertices += (long long)blockIdx.z * bs.vertices;
@@ -1128,52 +1133,65 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     const int cc = min(cell, cells - 1);
     const double vx = vertices[2 * cc], vy = vertices[2 * cc + 1];
     const int nchunks = (n + kChunk - 1) / kChunk;
+    const int nrounds = (nchunks + kRing - 1) / kRing;
 
     constexpr int kPieces = kChunk * 16 / 256;
-    double2 stage[kPieces];
-    auto load_chunk = [&](int c) {
+    double2 stage[kRing][kPieces];
+    auto load_round = [&](int r) {
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int q = tid + 256 * i;
-            const int p = c * kChunk + (q >> 4);
-            stage[i] = (p < n) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
-                               : make_double2(0.0, 0.0);
+        for (int b = 0; b < kRing; ++b) {
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int q = tid + 256 * i;
+                const int p = (r * kRing + b) * kChunk + (q >> 4);
+                stage[b][i] = (p < n) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
+                                      : make_double2(0.0, 0.0);  // zero rows add nothing whatever their weight
+            }
         }
     };
-    auto store_chunk = [&](int b) {
+    auto store_round = [&]() {
 #pragma unroll
-        for (int i = 0; i < kPieces; ++i) {
-            const int q = tid + 256 * i;
-            const int r = q >> 4;
-            const int slot = (q & 15) ^ ((r & 1) << 3);
-            *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[i];
+        for (int b = 0; b < kRing; ++b) {
+#pragma unroll
+            for (int i = 0; i < kPieces; ++i) {
+                const int q = tid + 256 * i;
+                const int r = q >> 4;
+                const int slot = (q & 15) ^ ((r & 1) << 3);
+                *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[b][i];
+            }
         }
     };
     const int off_xy = lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col), off_b1 = lds_off(kgrp, 16 + col);
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    load_chunk(0);
-    store_chunk(0);
+    load_round(0);
+    store_round();
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) load_chunk(c + 1);
-        const unsigned char *buf = lds[c & 1] + 1024 * wave;
-        double w2[kChunk / 16];  // this wave's steps: wave, wave + 4, wave + 8, wave + 12; weights first (see k_assemble_mfma)
+    for (int r = 0; r < nrounds; ++r) {
+        if (r + 1 < nrounds) load_round(r + 1);
+        const int live = min(kRing, nchunks - r * kRing);   // chunks of this round (block-uniform)
+        for (int b = 0; b < live; ++b) {
+            const unsigned char *buf = lds[b] + 1024 * wave;
+            double w2[kChunk / 16];  // this wave's steps: wave, wave + 4, wave + 8, wave + 12; weights first (see k_assemble_mfma)
 #pragma unroll
-        for (int i = 0; i < kChunk / 16; ++i) {
-            const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
-            w2[i] = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < kChunk / 16; ++i) {
+                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
+                w2[i] = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < kChunk / 16; ++i) {
-            const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
-            const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b1, acc1, 0, 0, 0);
+            for (int i = 0; i < kChunk / 16; ++i) {
+                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
+                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b1, acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nchunks) store_chunk((c + 1) & 1);
-        __syncthreads();
+        __syncthreads();                                    // every wave is done reading the ring
+        if (r + 1 < nrounds) {
+            store_round();
+            __syncthreads();
+        }
     }
     // cross-wave reduction through LDS (the chunk buffers are free now): part[wave][cell][32 moments].
     // D layout: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15] = (cell, moment)
