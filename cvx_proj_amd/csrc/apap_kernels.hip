@@ -614,8 +614,10 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
 // --------------------------------------------------------------------------------
 // K2: per-cell symmetric 9x9 eigen-solve, lanes = cells, everything in registers: inverse
 // iteration on an L D L^T factorisation by default, cyclic Jacobi sweeps (45 + 81 doubles)
-// as the fallback and as the selectable alternative; then the eigenvector of the smallest
-// eigenvalue is de-normalised (apap.py:161-168) and stored as float32.
+// as the fallback and as the selectable alternative; cells whose normal matrix cannot carry the
+// answer (eigen-gap below 1e-4 of the trace, underflowed sums, fewer than 5 keypoints) are re-solved
+// from the weighted rows themselves (qr_resolve); then the vector is de-normalised
+// (apap.py:161-168) and stored as float32.
 // --------------------------------------------------------------------------------
 __host__ __device__ constexpr int tri(int i, int j) {
     return i <= j ? i * (19 - i) / 2 + (j - i) : j * (19 - j) / 2 + (i - j);
