@@ -479,6 +479,7 @@ def main():
             cs.warp()
         tc_solve = timed(cs.solve, a.steps)
         tc_warp = timed(cs.warp, a.steps)
+        tc_bands = timed(lambda: cs.warp(gather=False), a.steps)      # the canvas left distributed: no collective
         assert int(cs.status.cpu()[0]) == 0
         ctx.set("profile", 1)
         for _ in range(min(a.steps, 10)):
@@ -497,7 +498,12 @@ def main():
             "scaling": "strong", "value": cs.cells_total * a.steps / tc_solve, "unit": "homographies/s",
             "solve_ms_per_step": tc_solve / a.steps * 1e3,
             "warp": {"value": cp.final_w * cp.final_h * a.steps / tc_warp / 1e6, "unit": "Mpix/s",
-                     "ms_per_step": tc_warp / a.steps * 1e3},
+                     "ms_per_step": tc_warp / a.steps * 1e3,
+                     "note": "row bands + all-gather: the whole canvas on every rank after every step"},
+            "warp_bands_only": {"value": cp.final_w * cp.final_h * a.steps / tc_bands / 1e6, "unit": "Mpix/s",
+                                "ms_per_step": tc_bands / a.steps * 1e3,
+                                "note": "row bands left where they are computed (no collective): the part of the warp that "
+                                        "shards; SURVEY.md 8e expects the gathered form to be transfer-dominated"},
             "table_broadcast_ms": t_bcast * 1e3, "first_warp_incl_image_broadcast_ms": t_first_warp * 1e3,
             "collectives_per_step": "solve: 1 all-gather of the H grid (36 B per cell); warp: 1 all-gather of the canvas bands"
                                     if world > 1 else "none",

@@ -175,10 +175,14 @@ class ShardedSolver:
         self._bands = torch.zeros((self.world, self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
         self.out = torch.zeros((p.final_h, p.final_w, 3), dtype=torch.uint8, device=self.dev)
 
-    def warp(self, stream=None):
+    def warp(self, stream=None, gather=True):
         """Backward warp of the pair with canvas rows sharded over the ranks: every rank
         warps its band from the full H grid (present on every rank after ``solve``), one
-        all-gather assembles the canvas on every rank.  Returns ``self.out``."""
+        all-gather assembles the canvas on every rank.  Returns ``self.out``.
+
+        ``gather=False`` stops after the band: the canvas stays distributed (rank r holds rows
+        ``self.bands[r]`` in ``self._band``) - what a pipeline that writes or consumes the bands in
+        place does, and the part of the step that scales; returns this rank's band."""
         if not hasattr(self, "img"):
             self._warp_setup()
         p, d = self.pair, self.dist
@@ -190,6 +194,8 @@ class ShardedSolver:
             self.status = st
         if single:
             return self.out
+        if not gather:
+            return self._band[:b - a]
         if all(rb - ra == b - a for ra, rb in self.bands):
             d.all_gather_into_tensor(self.out, self._band[:b - a])
             return self.out

@@ -32,6 +32,9 @@ def main():
     canvas = s.warp().cpu().numpy().copy()
     H2 = s.solve().cpu().numpy()                          # a second solve does not broadcast again and gives the same grid
     assert np.array_equal(H, H2)
+    band = s.warp(gather=False).cpu().numpy()             # the canvas left distributed: this rank's rows only
+    lo, hi = s.bands[rank]
+    assert np.array_equal(band, canvas[lo:hi])
     pairs = [config_pair("C1", with_image=False, seed_offset=k) for k in range(5)]
     grids = solve_pairs(pairs, dev, dist)
     gathered = [None] * world

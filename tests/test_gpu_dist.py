@@ -71,5 +71,6 @@ def test_bench_self_launch_reports_pairs_and_cells(native):
     assert c["world_size"] == 2 and c["scaling"] == "strong" and c["backend"] == "gloo"
     assert c["rank0_cells"] == 50 * 100                               # half of the 100 x 100 mesh
     assert 0.0 < c["roofline"]["frac"] < 1.0 and c["value"] > 0 and c["warp"]["value"] > 0
+    assert c["warp_bands_only"]["value"] >= c["warp"]["value"] * 0.9      # the all-gather can only cost
     one = d["roofline"]["frac"]
     assert c["roofline"]["frac"] < 2.5 * one                          # not inflated by the world size
