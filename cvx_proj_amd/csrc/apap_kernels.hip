@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
 // K2: per-cell symmetric 9x9 eigen-solve, lanes = cells, everything in registers: inverse
 // iteration on an L D L^T factorisation by default, cyclic Jacobi sweeps (45 + 81 doubles)
 // as the fallback and as the selectable alternative; cells whose normal matrix cannot carry the
-// answer (eigen-gap below 1e-4 of the trace, underflowed sums, fewer than 5 keypoints) are re-solved
+// answer (eigen-gap below 1e-3 of the trace, underflowed sums, fewer than 5 keypoints) are re-solved
 // from the weighted rows themselves (qr_resolve); then the vector is de-normalised
 // (apap.py:161-168) and stored as float32.
 // --------------------------------------------------------------------------------
@@ -822,9 +822,10 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
 // - the SQUARE of what the SVD's eps * sigma_1 / (sigma_8 - sigma_9) is.  On the Hartley-normalised
 // systems of image data (lambda_8 - lambda_9) / trace sits at 1.5e-2 (C1-C5, every golden case); with
 // gamma = 0 and sigma of a few pixels the weights span 10+ orders of magnitude and it falls to
-// 1e-7 ... 1e-20 (soak seeds 544, 659, 795, 814, 883: hundreds of pixels off).  A cell whose gap is
-// below kGapTol * trace is re-solved from the weighted rows themselves (qr_resolve below).
-constexpr double kGapTol = 1e-4;  // normal-equation error ~ 50 eps / kGapTol = 1e-10 relative at the threshold
+// 1e-7 ... 1e-20 (soak seeds 544, 659, 795, 814, 883: hundreds of pixels off); nearly determined systems
+// (5-6 keypoints) sit at 4e-4 ... 3e-3.  A cell whose gap is below kGapTol * trace is re-solved from the
+// weighted rows themselves (qr_resolve below).
+constexpr double kGapTol = 1e-3;  // normal-equation error ~ 50 eps / kGapTol = 1e-11 relative at the threshold
 
 __device__ __forceinline__ double rcp_fast(double x) {  // ~2^-46: only signs of pivots are used
     const double r = __builtin_amdgcn_rcp(x);

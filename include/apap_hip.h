@@ -94,7 +94,7 @@ int apap_device_count(void);
 typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_SOLVER_VARIANT 0 /* APAP_VARIANT_*; default AUTO (= MFMA)                              */
 #define APAP_OPT_EIGEN_SOLVER 1   /* APAP_EIGEN_*; default AUTO                                         */
-#define APAP_OPT_CAREFUL 2        /* 1 (default): cells whose eigen-gap is below 1e-4 of the trace, and every
+#define APAP_OPT_CAREFUL 2        /* 1 (default): cells whose eigen-gap is below 1e-3 of the trace, and every
                                      cell when n < 5, are re-solved from the weighted 2n x 9 rows (Givens QR +
                                      one-sided Jacobi) as apap.py:159-161 does; 0: normal equations only    */
 #define APAP_OPT_PROFILE 3        /* 1: bracket every kernel with HIP events (apap_ctx_profile_read)     */
