@@ -78,6 +78,8 @@ def worker(rank, world, port, rows, q):
         assert float(s.table.abs().sum()) > 0.0                  # broadcast arrived
         canvas = s.warp().numpy().copy()                         # image broadcast + banded warp + all-gather
         assert s.bands[0][0] == 0 and s.bands[-1][1] == p.final_h
+        lo, hi = s.bands[rank]
+        assert np.array_equal(s.warp(gather=False).numpy(), canvas[lo:hi])   # the canvas left distributed: own rows only
         pairs = [synth_pair(320, 240, 60, 4, seed=100 + k) for k in range(5)]
         grids = solve_pairs(pairs, torch.device("cpu"), dist, solve_fn=oracle_solve)
         q.put((rank, s.parts, H, grids, canvas))
