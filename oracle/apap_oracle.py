@@ -38,6 +38,7 @@ __all__ = [
     "get_mesh", "get_vertice", "final_size", "uniform_blend",
     "normalize_2d_pts", "conditioner_from_pts", "point_normalize", "dlt_rows",
     "prepare", "cell_weights", "local_homography_loop", "local_homography_fast", "local_homography_pool",
+    "local_homography_exact_cell",
     "invert_cells_f32", "cell_lookup", "local_warp_loop", "local_warp_fast",
     "warp_coords_fast", "stitch", "invert_normalize_flatten", "project", "reprojection_rmse_delta",
 ]
@@ -220,6 +221,22 @@ def local_homography_loop(src_point, dst_point, vertices, gamma, sigma, cells=No
             gap = (sv[-2] - sv[-1]) if len(sv) > 1 else sv[-1]
             cond_out[i, j] = sv[0] / gap if gap > 0 else np.inf
     return H, W
+
+
+def local_homography_exact_cell(src_point, dst_point, vertex, gamma, sigma, digits=60):
+    """The reference's answer for ONE cell with its SVD taken in ``digits``-digit arithmetic (mpmath): the
+    same float64 matrix ``repeat(weight, 2)[:, None] * aa`` (apap.py:150-159), the last right singular
+    vector of its thin SVD, de-normalised with the reference's float32 matrices, float32 result.  The
+    arbiter where the engine and the reference's float64 LAPACK SVD disagree (test diagnostics only;
+    ~50 ms per cell)."""
+    import mpmath as mp
+    p = prepare(src_point, dst_point)
+    A = np.expand_dims(np.repeat(cell_weights(vertex, src_point, gamma, sigma), 2), -1) * p["aa"]
+    with mp.workdps(digits):
+        _, S, V = mp.svd_r(mp.matrix(A.tolist()), full_matrices=False, compute_uv=True)
+        k = min(range(len(S)), key=lambda i: S[i])
+        v = np.array([float(V[k, j]) for j in range(9)])
+    return _denormalise(v, p).astype(np.float32)
 
 
 def _pool_worker(args):

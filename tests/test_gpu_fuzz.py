@@ -5,13 +5,14 @@ perspective, negative offsets)."""
 import numpy as np
 import pytest
 
+from conftest import ulp_diff_f32
 from oracle import apap_oracle as O
 
 pytestmark = pytest.mark.gpu
 # forward error of a singular vector from a normwise backward-stable float64 SVD of a 2n x 9 matrix:
-# REF_SVD_ERR * eps * sigma_1 / gap (LAPACK's backward error constant is a modest multiple of eps).
-# Calibrated on an 8000-seed soak (tools/long_fuzz.py 40 8000): with 32 one seed (6607) exceeded the bound by
-# a factor 1.17 in a cell where the engine equals the 60-digit answer and the reference is 2.9e-4 px off.
+# REF_SVD_ERR * eps * sigma_1 / gap (LAPACK's backward error constant is a modest multiple of eps); used by
+# test_more_accurate_than_the_reference_where_it_is_lost to show that the reference's distance from the exact
+# answer is of the size its conditioning predicts.
 REF_SVD_ERR = 128.0
 
 
@@ -44,7 +45,10 @@ def random_case(seed):
                 gamma=gamma, sigma=sigma, shape=(rows, cols), n=n)
 
 
-@pytest.mark.parametrize("seed", range(40))
+# 6607, 16739: cells where the reference's float64 SVD is 1.1e-4 ... 2.9e-4 px from the exact answer and the
+# engine equals it; 22280: one float32 value of 5994 differs by one unit in the last place, 8e-4 px at a
+# perspective gain of 14 (found by tools/long_fuzz.py over seeds 40 ... 29 000)
+@pytest.mark.parametrize("seed", list(range(40)) + [6607, 16739, 22280])
 def test_fuzz_solve_and_warp(native, seed):
     c = random_case(1000 + seed)
     H, W = native.local_homography(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"])
@@ -59,20 +63,31 @@ def test_fuzz_solve_and_warp(native, seed):
     # from the weighted rows by K2), a relative 1e-5 to the blown-up ones.
     scale = np.abs(O.project(H_ref[ok], c["src"])).max(axis=(1, 2))
     sane = scale < 50.0 * max(c["img"].shape[:2])
-    # The reference's own float64 SVD is only determined to eps * sigma_1 / (sigma_8 - sigma_9) (its
-    # LAPACK routine is normwise backward stable, no better): with gamma = 0, sigma = 3 px and 5-6
-    # keypoints that reaches 1e-3 ... 1 and the REFERENCE is px away from the exact answer (a 5000-seed
-    # soak found 12 such inputs; on each the engine's careful path equals a 60-digit SVD after float32
-    # rounding - test_more_accurate_than_the_reference_where_it_is_lost).  Where the reference's error
-    # bound exceeds a tenth of the bar, the bar is that bound.
-    ref_err = REF_SVD_ERR * np.finfo(np.float64).eps * cond[ok] * np.maximum(scale, 1.0)
-    bar = np.maximum(1e-4, ref_err)
+    # Where a sane cell misses the flat bar, it must be for one of two reasons that are not the engine's:
+    # (1) float32 storage: the reference stores float32 (apap.py:168) and one unit in the last place of
+    #     an entry moves keypoints by ulp * coordinate * perspective gain - above 1e-4 px as soon as the
+    #     projected coordinates reach the thousands (a 26 000-seed soak met two such cells: the engine's and
+    #     the reference's float64 results straddle a float32 rounding boundary);
+    # (2) the reference's own float64 SVD is lost: LAPACK's routine is normwise backward stable, no better,
+    #     so its vector is off by eps * sigma_1 / (sigma_8 - sigma_9); with gamma = 0, sigma = 3 px and 5-6
+    #     keypoints that reaches 1e-3 ... 1 and the REFERENCE is px away from the exact answer
+    #     (test_more_accurate_than_the_reference_where_it_is_lost).  There the arbiter is the reference's
+    #     own matrix with its SVD taken in 60-digit arithmetic (oracle: local_homography_exact_cell).
     print(f"seed {seed}: n={c['n']} mesh={c['shape']} max delta {d.max():.2e} px, sane cells {int(sane.sum())}/{sane.size}, "
-          f"float32 values differing {int((H[ok] != H_ref[ok]).sum())}, cells where the reference is not determined to "
-          f"1e-5 px: {int((ref_err > 1e-5).sum())}")
-    assert (d / np.maximum(scale, 1.0) < np.maximum(1e-5, ref_err / np.maximum(scale, 1.0))).all(), f"seed {seed}: {d.max()}"
-    if sane.any():
-        assert (d[sane] < bar[sane]).all(), f"seed {seed}: {(d[sane] / bar[sane]).max()} x the bar, {d[sane].max()} px"
+          f"float32 values differing {int((H[ok] != H_ref[ok]).sum())}")
+    cells_ok = np.argwhere(ok)
+    bar = np.where(sane, 1e-4, 1e-5 * np.maximum(scale, 1.0))
+    for k in np.flatnonzero(d >= bar):
+        i, j = cells_ok[k]
+        if ulp_diff_f32(H[i, j], H_ref[i, j]).max() <= 1:
+            continue                                                 # (1) equal up to the float32 rounding of the store
+        exact = O.local_homography_exact_cell(c["src"], c["dst"], c["verts"][i, j], c["gamma"], c["sigma"])
+        d_exact = float(O.reprojection_rmse_delta(H[i, j], exact, c["src"]))
+        d_ref_exact = float(O.reprojection_rmse_delta(H_ref[i, j], exact, c["src"]))
+        print(f"   cell ({i},{j}): engine vs reference {d[k]:.2e} px; engine vs exact {d_exact:.2e}, reference vs exact "
+              f"{d_ref_exact:.2e}; sigma_1 / gap {cond[i, j]:.1e}")
+        assert d_exact < bar[k] or ulp_diff_f32(H[i, j], exact).max() <= 1, f"seed {seed} cell ({i},{j}): {d_exact} px from the exact answer"
+        assert d_ref_exact >= 0.5 * d[k], f"seed {seed} cell ({i},{j}): the disagreement is not the reference's error"     # (2)
     # warp with the REFERENCE homographies (so the comparison isolates the warp)
     fw, fh = c["canvas"]
     ox, oy = c["off"]
