@@ -19,6 +19,10 @@
 
 #include "apap_internal.h"
 
+#ifdef APAP_TRACE_SMALL
+__device__ long long g_tq[16];
+#define APAP_STAMP(i) do { if (blockIdx.x == 3 && threadIdx.x == 0) g_tq[i] = clock64(); } while (0)
+#endif
 namespace {
 
 using apap::kMoments;
@@ -383,7 +387,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
     vertices += (long long)blockIdx.z * bs.vertices;
     moments += (long long)blockIdx.z * bs.moments;
     __shared__ double s_exp2[kExpN];
-    for (int j = threadIdx.x; j < kExpN; j += kWaves * 64) s_exp2[j] = kExp2Tab[j];  // visible after the first barrier
+    // The exp table goes through registers and is written to LDS AFTER the first chunk's loads have been
+    // issued: `s_exp2[j] = kExp2Tab[j]` up here made the block wait out one global-memory latency before
+    // it even asked for its keypoints (two latencies in a row; it shows on small meshes).
+    static_assert(kExpN % (kWaves * 64) == 0 || (kWaves * 64) % kExpN == 0, "exp table vs block size");
+    constexpr int kExpPerThread = (kExpN + kWaves * 64 - 1) / (kWaves * 64);
+    double exp_stage[kExpPerThread];
+#pragma unroll
+    for (int i = 0; i < kExpPerThread; ++i) exp_stage[i] = kExp2Tab[(threadIdx.x + i * kWaves * 64) & (kExpN - 1)];
     const double scaled_inv_sigma2 = inv_sigma2 * kExpScale;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -424,10 +435,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
 
     const int off_xy = lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col), off_b1 = lds_off(kgrp, 16 + col);
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
+    if (nchunks > 0) load_chunk(0);
+#pragma unroll
+    for (int i = 0; i < kExpPerThread; ++i) s_exp2[(tid + i * kThreads) & (kExpN - 1)] = exp_stage[i];  // visible after the barrier
+    if (nchunks > 0) store_chunk(0);
     __syncthreads();
     // Drain the prologue's loads (vertex, first chunk) here: otherwise the compiler's wait
     // for the vertex registers lands inside the step loop as vmcnt(0) and also waits for
@@ -436,7 +447,21 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
     for (int c = 0; c < nchunks; ++c) {
         if (c + 1 < nchunks) load_chunk(c + 1);
         const unsigned char *buf = lds[c & 1];
-        // a partial last chunk runs all 16 steps: its missing rows are zero
+        // A partial last chunk runs only the steps that hold keypoints (its missing rows are zero and would
+        // add +0 to every sum, at the full price of a step: C3's 1000 keypoints per split are 15 chunks
+        // and 10 steps of the 16th - 2.3 % of the kernel).  Same MFMAs in the same order: identical sums.
+        const int steps_here = min(kChunk / 4, (p_end - p_begin - c * kChunk + 3) >> 2);
+        if (steps_here < kChunk / 4) {
+            for (int s1 = 0; s1 < steps_here; ++s1) {
+                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * s1);
+                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * s1);
+                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * s1);
+                const double w2 = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
+            }
+            break;   // fewer than 64 keypoints left: this was the last chunk
+        }
 #if APAP_K1_GROUP > 1
         // The weights of g steps first, then their 2 g MFMAs back to back: g times fewer MFMA <-> VALU
         // transitions (~10 issue cycles each, profiles/r02_coexec.txt) and g independent weight chains
@@ -739,47 +764,98 @@ constexpr int kMaxInvIt = 12;
 
 __host__ __device__ constexpr int low(int i, int j) { return i * (i - 1) / 2 + j; }  // strict lower, i > j
 
-__device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double (&h)[9], double &rho) {
+// 1 / x to <= 1 ulp (v_rcp_f64 + two Newton steps: 5 instructions where the IEEE division sequence is 12).
+// inf / NaN / 0 in -> NaN or inf out; the callers test their operands.
+__device__ __forceinline__ double rcp_full(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// 1 / sqrt(x) to ~1 ulp (v_rsq_f64 + two Newton steps)
+__device__ __forceinline__ double rsqrt_full(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return fma(y, fma(-hx * y, y, 0.5), y);
+}
+
+// The normal matrix is [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]] (3x3 blocks): rows 3..5 of its unit
+// lower factor are zero in columns 0..2 and repeat rows 0..2 next to them, with the same pivots.  The
+// factorisation and the two triangular solves below skip the products with those exact zeros (a term
+// 0 * t added by an FMA changes nothing) and copy the repeated block: the same numbers as the dense
+// recurrences, bit for bit, in 145 instead of ~300 instructions and 27 instead of 36 per solve.
+__host__ __device__ constexpr bool lnz(int i, int k) { return !(i >= 3 && i <= 5 && k <= 2); }  // l(i, k) != 0 structurally
+
+__device__ __forceinline__ int count_eigs_below(const double (&m)[kMoments], double mu);
+
+// `below` (when m is given): the number of eigenvalues below (an upper bound of lambda_9) + gap_tol - the
+// conditioning guard of eigen_denorm_cell.  It is evaluated at the top of the third solve with the
+// Rayleigh bound of the second (exact to ~1e-10 relative by then) so that its ~100 instructions - six
+// reciprocals in a row - fill the issue slots that the solve's dependent chains leave empty, instead of
+// standing alone after the loop (K2 runs one wave per SIMD: nothing else hides latency there).
+__device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double (&h)[9], double &rho,
+                                                  const double (&m)[kMoments], double gap_tol, int &below) {
     double l[36], d[9], rd[9];  // unit lower factor, pivots and their reciprocals
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         double t[9];  // t[k] = l(j,k) * d[k]
-        double dj = a[tri(j, j)];
+        if (j >= 3 && j <= 5) {  // the second copy of S0's factor
+            d[j] = d[j - 3];
+            rd[j] = rd[j - 3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            if (k < j) {
-                t[k] = l[low(j, k)] * d[k];
-                dj = fma(-l[low(j, k)], t[k], dj);
+            for (int k = 3; k < 9; ++k)
+                if (k < j) t[k] = l[low(j, k)] * d[k];
+        } else {
+            double dj = a[tri(j, j)];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (k < j) {
+                    t[k] = l[low(j, k)] * d[k];
+                    dj = fma(-l[low(j, k)], t[k], dj);
+                }
             }
+            ok = ok && (dj > 0.0) && (dj < 1e300);
+            d[j] = dj;
+            rd[j] = rcp_full(dj);
         }
-        ok = ok && (dj > 0.0) && (dj < 1e300);
-        d[j] = dj;
-        rd[j] = 1.0 / dj;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             if (i > j) {
-                double sum = a[tri(j, i)];
+                if (!lnz(i, j)) {
+                    l[low(i, j)] = 0.0;  // never read
+                } else if (i <= 5 && j >= 3) {
+                    l[low(i, j)] = l[low(i - 3, j - 3)];
+                } else {
+                    double sum = a[tri(j, i)];
 #pragma unroll
-                for (int k = 0; k < 9; ++k)
-                    if (k < j) sum = fma(-l[low(i, k)], t[k], sum);
-                l[low(i, j)] = sum * rd[j];
+                    for (int k = 0; k < 9; ++k)
+                        if (k < j && lnz(i, k) && lnz(j, k)) sum = fma(-l[low(i, k)], t[k], sum);
+                    l[low(i, j)] = sum * rd[j];
+                }
             }
         }
     }
+#ifdef APAP_TRACE_SMALL
+    APAP_STAMP(8);
+    int its = 0;
+#endif
     double v[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = 1.0 / 3.0;
     bool done = false;
     double vMv = 1.0;  // v^T M^-1 v of the last step: 1 / vMv >= lambda_min (Rayleigh quotient of M^-1)
+    below = -1;
     for (int it = 0; it < kMaxInvIt; ++it) {
+        if (it == 2) below = count_eigs_below(m, rcp_full(vMv) + gap_tol);
         double y[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) {  // L z = v
             double sum = v[i];
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                if (k < i) sum = fma(-l[low(i, k)], y[k], sum);
+                if (k < i && lnz(i, k)) sum = fma(-l[low(i, k)], y[k], sum);
             y[i] = sum;
         }
 #pragma unroll
@@ -789,7 +865,7 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
             double sum = y[i];
 #pragma unroll
             for (int k = 0; k < 9; ++k)
-                if (k > i) sum = fma(-l[low(k, i)], y[k], sum);
+                if (k > i && lnz(k, i)) sum = fma(-l[low(k, i)], y[k], sum);
             y[i] = sum;
         }
         double nrm2 = 0.0, dot = 0.0;
@@ -798,7 +874,7 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
             nrm2 = fma(y[i], y[i], nrm2);
             dot = fma(y[i], v[i], dot);
         }
-        const double scale = copysign(1.0, dot) / sqrt(nrm2);
+        const double scale = copysign(rsqrt_full(nrm2), dot);
         vMv = fabs(dot);
         double change = 0.0;
 #pragma unroll
@@ -807,12 +883,20 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
             change = fmax(change, fabs(yn - v[i]));
             v[i] = yn;
         }
-        done = change <= 1e-14;  // false for NaN
+        done = change <= 1e-14;  // false for NaN; the error left is that times lambda_9 / lambda_8
+#ifdef APAP_TRACE_SMALL
+        ++its;
+#endif
         if (__all(done || !ok)) break;
     }
+#ifdef APAP_TRACE_SMALL
+    APAP_STAMP(9);
+    if (blockIdx.x == 3 && threadIdx.x == 0) g_tq[15] = its;
+#endif
 #pragma unroll
     for (int k = 0; k < 9; ++k) h[k] = v[k];
-    rho = 1.0 / vMv;
+    rho = rcp_full(vMv);
+    if (below < 0) below = count_eigs_below(m, rho + gap_tol);  // converged in two solves: wave-uniform, practically never
     return ok && done;
 }
 
@@ -1030,6 +1114,9 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
         }
     a[tri(6, 6)] = m[24]; a[tri(6, 7)] = m[25]; a[tri(6, 8)] = m[26];
     a[tri(7, 7)] = m[27]; a[tri(7, 8)] = m[28]; a[tri(8, 8)] = m[29];
+#ifdef APAP_TRACE_SMALL
+    APAP_STAMP(0);
+#endif
     const double trace = 2.0 * (m[0] + m[3] + m[5]) + m[24] + m[27] + m[29];
     const double gap_tol = kGapTol * trace;
     // The sums are of w^2: where every weight is below ~1e-140 they underflow (partly or entirely)
@@ -1044,10 +1131,17 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
     bool careful_cell = careful && (pick_rank != 0 || underflowed);
     if (kUseInverseIteration && pick_rank == 0) {
         double rho;
-        have = inverse_iteration(a, h, rho);
+        int below;
+        have = inverse_iteration(a, h, rho, m, gap_tol, below);
+#ifdef APAP_TRACE_SMALL
+        APAP_STAMP(1);
+#endif
         // a second eigenvalue within gap_tol of the smallest?  (rho >= lambda_9, so lambda_9 counts)
-        if (careful && !careful_cell) careful_cell = have && count_eigs_below(m, rho + gap_tol) >= 2;
+        if (careful && !careful_cell) careful_cell = have && below >= 2;
     }
+#ifdef APAP_TRACE_SMALL
+    APAP_STAMP(2);
+#endif
     if (!__all(have || careful_cell)) {  // rare: no spectral gap, pivot not positive (n < 5 with careful == 0)
         double hj[9];
         const double gap = jacobi_eigvec(a, pick_rank, hj);
@@ -1061,15 +1155,41 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = careful_cell ? hq[k] : h[k];
     }
+#ifdef APAP_TRACE_SMALL
+    APAP_STAMP(3);
+#endif
     double t1[9], t2[9];
     mul3(denorm, h, t1);        // inv(C2) . h
     mul3(t1, denorm + 9, t2);   // . C1
     mul3(denorm + 18, t2, t1);  // inv(N2) .
     mul3(t1, denorm + 27, t2);  // . N1
     if (out) {
+        // h / h[2,2] (apap.py:167): one reciprocal and a residual correction per quotient (the Markstein
+        // sequence of k_warp_rows: the correctly rounded quotient) instead of nine IEEE division sequences;
+        // anything out of the ordinary (h[2,2] zero / tiny / huge / NaN, an overflowing quotient) takes those.
+        const double r8 = rcp_full(t2[8]);
+        double q[9];
+        bool plain = fabs(t2[8]) >= 1e-290 && fabs(t2[8]) <= 1e290;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) out[k] = (float)(t2[k] / t2[8]);
+        for (int k = 0; k < 8; ++k) {
+            const double q0 = t2[k] * r8;
+            q[k] = fma(fma(-t2[8], q0, t2[k]), r8, q0);
+            plain = plain && fabs(q[k]) <= 1e290;
+        }
+        q[8] = 1.0;
+        if (!__all(plain)) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) q[k] = plain ? q[k] : t2[k] / t2[8];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = (float)q[k];
     }
+#ifdef APAP_TRACE_SMALL
+    APAP_STAMP(4);
+    if (blockIdx.x == 3 && threadIdx.x == 0)
+        printf("  tail: build+factorise %lld  %lld solves %lld  guard %lld  votes %lld  denorm+store %lld\n", g_tq[8] - g_tq[0], g_tq[15],
+               g_tq[9] - g_tq[8], g_tq[2] - g_tq[1], g_tq[3] - g_tq[2], g_tq[4] - g_tq[3]);
+#endif
 }
 
 // K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
@@ -1126,7 +1246,15 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     denorm += (long long)blockIdx.z * bs.denorm;
     H += (long long)blockIdx.z * bs.H;
     const int tid = threadIdx.x;
-    for (int j = tid; j < kExpN; j += 256) s_exp2[j] = kExp2Tab[j];
+#ifdef APAP_TRACE_SMALL
+    long long tr[6];
+    tr[0] = clock64();
+#endif
+    const double exp_stage[2] = {kExp2Tab[tid], kExp2Tab[tid + 256]};   // to LDS after the first round's loads are issued
+    // the four de-normalisation matrices too: the tail would otherwise wait for them (cold scalar loads) at its very end
+    __shared__ double s_denorm[APAP_DENORM_DOUBLES];
+    const double den_stage = denorm[min(tid, APAP_DENORM_DOUBLES - 1)];
+    static_assert(kExpN == 512, "two table entries per thread");
     const double gamma2 = gamma > 0.0 ? gamma * gamma : 0.0;
     const double scaled_inv_sigma2 = 2.0 * inv_sigma * kExpScale;
     const int lane = tid & 63;
@@ -1167,13 +1295,32 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     const int off_xy = lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col), off_b1 = lds_off(kgrp, 16 + col);
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     load_round(0);
+    s_exp2[tid] = exp_stage[0];
+    s_exp2[tid + 256] = exp_stage[1];
+    if (tid < APAP_DENORM_DOUBLES) s_denorm[tid] = den_stage;
     store_round();
     __syncthreads();
+#ifdef APAP_TRACE_SMALL
+    tr[1] = clock64();
+#endif
     for (int r = 0; r < nrounds; ++r) {
         if (r + 1 < nrounds) load_round(r + 1);
         const int live = min(kRing, nchunks - r * kRing);   // chunks of this round (block-uniform)
         for (int b = 0; b < live; ++b) {
             const unsigned char *buf = lds[b] + 1024 * wave;
+            // only the steps that hold keypoints (see k_assemble_mfma): C1's 150 keypoints are 2 chunks and 6 steps
+            const int steps_here = min(kChunk / 4, (n - (r * kRing + b) * kChunk + 3) >> 2);
+            if (steps_here < kChunk / 4) {
+                for (int i = 0; wave + 4 * i < steps_here; ++i) {
+                    const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
+                    const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
+                    const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
+                    const double w2s = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2s, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2s, b1, acc1, 0, 0, 0);
+                }
+                continue;
+            }
             double w2[kChunk / 16];  // this wave's steps: wave, wave + 4, wave + 8, wave + 12; weights first (see k_assemble_mfma)
 #pragma unroll
             for (int i = 0; i < kChunk / 16; ++i) {
@@ -1199,6 +1346,9 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     // cross-wave reduction through LDS (the chunk buffers are free now): part[wave][cell][32 moments].
     // D layout: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15] = (cell, moment)
     double *part = reinterpret_cast<double *>(&lds[0][0]);
+#ifdef APAP_TRACE_SMALL
+    tr[2] = clock64();
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ci = kgrp + 4 * i;
@@ -1207,13 +1357,22 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     }
     __syncthreads();
     if (wave != 0 || lane >= 16) return;       // lanes 0..15 of wave 0 = the block's 16 cells
+#ifdef APAP_TRACE_SMALL
+    tr[3] = clock64();
+#endif
     double m[kMoments];
 #pragma unroll
     for (int j = 0; j < kMoments; ++j)
         m[j] = ((part[(0 * 16 + lane) * 32 + j] + part[(1 * 16 + lane) * 32 + j]) + part[(2 * 16 + lane) * 32 + j]) +
                part[(3 * 16 + lane) * 32 + j];
-    eigen_denorm_cell<kUseInverseIteration>(m, denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
+    eigen_denorm_cell<kUseInverseIteration>(m, s_denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
                                             cell < cells ? H + (size_t)cell * 9 : nullptr);
+#ifdef APAP_TRACE_SMALL
+    tr[4] = clock64();
+    if (blockIdx.x == 3 && tid == 0)
+        printf("k_solve_small block 3: prologue %lld  loop %lld  reduce %lld  tail %lld cycles (s_memtime)\n", tr[1] - tr[0],
+               tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3]);
+#endif
 }
 
 // --------------------------------------------------------------------------------
