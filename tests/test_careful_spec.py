@@ -54,3 +54,18 @@ def test_spec_on_well_conditioned_and_short_systems(golden):
         gamma, sigma = (float(v) for v in e[f"par{k}"])
         H = K.local_homography_careful(e[f"src{k}"], e[f"dst{k}"], e[f"verts{k}"], gamma, sigma)
         assert np.array_equal(H, e[f"H{k}"]), k
+
+
+def test_exact_cell_arbiter_reproduces_the_committed_exact_answers(golden):
+    """oracle.local_homography_exact_cell (the arbiter of the GPU fuzz test) against the 60-digit answers that
+    tests/golden/make_golden.py stored: same float32 matrices."""
+    pytest.importorskip("mpmath")
+    g = golden("illcond_truth")
+    seed = 5634
+    c = random_case(1000 + seed)
+    cells, exact = g[f"cells{seed}"], g[f"exact{seed}"]
+    cols = c["verts"].shape[1]
+    for k in (0, len(cells) // 2, len(cells) - 1):
+        i, j = int(cells[k] // cols), int(cells[k] % cols)
+        mine = O.local_homography_exact_cell(c["src"], c["dst"], c["verts"][i, j], c["gamma"], c["sigma"])
+        assert np.array_equal(mine, exact[k]), (k, mine, exact[k])
