@@ -1193,8 +1193,11 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
 }
 
 // K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
+#ifndef APAP_K2_WAVES_ATTR
+#define APAP_K2_WAVES_ATTR
+#endif
 template <bool kUseInverseIteration>
-__global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
+__global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const double *__restrict__ moments, int splits,
                                                      int cells, int cells_pad,
                                                      const double *__restrict__ denorm, int pick_rank,
                                                      float *__restrict__ H, BatchStride bs,
@@ -1229,8 +1232,14 @@ __global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ 
 // as many blocks as K1 would start.  Register use is the K2 tail's (one wave per SIMD): fine for the
 // few dozen to few hundred blocks this kernel is dispatched for.
 // --------------------------------------------------------------------------------
+#ifndef APAP_SMALL_WAVES
+#define APAP_SMALL_WAVES 4
+#endif
+constexpr int kSmallWaves = APAP_SMALL_WAVES;       // waves of a fused block: they split every chunk's 16 steps
+constexpr int kSmallThreads = kSmallWaves * 64;
+static_assert(kSmallWaves == 4 || kSmallWaves == 8, "the chunk's 16 steps and the staging split evenly over 4 or 8 waves");
 template <bool kUseInverseIteration>
-__global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ table, int n,
+__global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__restrict__ table, int n,
                                                      const double *__restrict__ vertices, int cells, double gamma,
                                                      double inv_sigma, const double *__restrict__ denorm, int pick_rank,
                                                      int careful, float *__restrict__ H, BatchStride bs) {
@@ -1250,11 +1259,14 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     long long tr[6];
     tr[0] = clock64();
 #endif
-    const double exp_stage[2] = {kExp2Tab[tid], kExp2Tab[tid + 256]};   // to LDS after the first round's loads are issued
+    constexpr int kExpPerThread = kExpN / kSmallThreads;
+    double exp_stage[kExpPerThread];   // to LDS after the first round's loads are issued
+#pragma unroll
+    for (int i = 0; i < kExpPerThread; ++i) exp_stage[i] = kExp2Tab[tid + i * kSmallThreads];
     // the four de-normalisation matrices too: the tail would otherwise wait for them (cold scalar loads) at its very end
     __shared__ double s_denorm[APAP_DENORM_DOUBLES];
     const double den_stage = denorm[min(tid, APAP_DENORM_DOUBLES - 1)];
-    static_assert(kExpN == 512, "two table entries per thread");
+    static_assert(kExpN % kSmallThreads == 0, "exp table entries per thread");
     const double gamma2 = gamma > 0.0 ? gamma * gamma : 0.0;
     const double scaled_inv_sigma2 = 2.0 * inv_sigma * kExpScale;
     const int lane = tid & 63;
@@ -1266,14 +1278,14 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     const int nchunks = (n + kChunk - 1) / kChunk;
     const int nrounds = (nchunks + kRing - 1) / kRing;
 
-    constexpr int kPieces = kChunk * 16 / 256;
+    constexpr int kPieces = kChunk * 16 / kSmallThreads;
     double2 stage[kRing][kPieces];
     auto load_round = [&](int r) {
 #pragma unroll
         for (int b = 0; b < kRing; ++b) {
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) {
-                const int q = tid + 256 * i;
+                const int q = tid + kSmallThreads * i;
                 const int p = (r * kRing + b) * kChunk + (q >> 4);
                 stage[b][i] = (p < n) ? *reinterpret_cast<const double2 *>(table + (size_t)p * APAP_TABLE_STRIDE + 2 * (q & 15))
                                       : make_double2(0.0, 0.0);  // zero rows add nothing whatever their weight
@@ -1285,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
         for (int b = 0; b < kRing; ++b) {
 #pragma unroll
             for (int i = 0; i < kPieces; ++i) {
-                const int q = tid + 256 * i;
+                const int q = tid + kSmallThreads * i;
                 const int r = q >> 4;
                 const int slot = (q & 15) ^ ((r & 1) << 3);
                 *reinterpret_cast<double2 *>(&lds[b][r * 256 + slot * 16]) = stage[b][i];
@@ -1295,8 +1307,8 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
     const int off_xy = lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col), off_b1 = lds_off(kgrp, 16 + col);
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     load_round(0);
-    s_exp2[tid] = exp_stage[0];
-    s_exp2[tid + 256] = exp_stage[1];
+#pragma unroll
+    for (int i = 0; i < kExpPerThread; ++i) s_exp2[tid + i * kSmallThreads] = exp_stage[i];
     if (tid < APAP_DENORM_DOUBLES) s_denorm[tid] = den_stage;
     store_round();
     __syncthreads();
@@ -1311,27 +1323,28 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
             // only the steps that hold keypoints (see k_assemble_mfma): C1's 150 keypoints are 2 chunks and 6 steps
             const int steps_here = min(kChunk / 4, (n - (r * kRing + b) * kChunk + 3) >> 2);
             if (steps_here < kChunk / 4) {
-                for (int i = 0; wave + 4 * i < steps_here; ++i) {
-                    const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
-                    const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
-                    const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
+                for (int i = 0; wave + kSmallWaves * i < steps_here; ++i) {
+                    const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * kSmallWaves * i);
+                    const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * kSmallWaves * i);
+                    const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * kSmallWaves * i);
                     const double w2s = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
                     acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2s, b0, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2s, b1, acc1, 0, 0, 0);
                 }
                 continue;
             }
-            double w2[kChunk / 16];  // this wave's steps: wave, wave + 4, wave + 8, wave + 12; weights first (see k_assemble_mfma)
+            constexpr int kMine = kChunk / 4 / kSmallWaves;
+            double w2[kMine];  // this wave's steps: wave, wave + kSmallWaves, ...; weights first (see k_assemble_mfma)
 #pragma unroll
-            for (int i = 0; i < kChunk / 16; ++i) {
-                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 4096 * i);
+            for (int i = 0; i < kMine; ++i) {
+                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * kSmallWaves * i);
                 w2[i] = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < kChunk / 16; ++i) {
-                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 4096 * i);
-                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 4096 * i);
+            for (int i = 0; i < kMine; ++i) {
+                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * kSmallWaves * i);
+                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * kSmallWaves * i);
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[i], b1, acc1, 0, 0, 0);
             }
@@ -1362,9 +1375,12 @@ __global__ __launch_bounds__(256) void k_solve_small(const double *__restrict__ 
 #endif
     double m[kMoments];
 #pragma unroll
-    for (int j = 0; j < kMoments; ++j)
-        m[j] = ((part[(0 * 16 + lane) * 32 + j] + part[(1 * 16 + lane) * 32 + j]) + part[(2 * 16 + lane) * 32 + j]) +
-               part[(3 * 16 + lane) * 32 + j];
+    for (int j = 0; j < kMoments; ++j) {   // the waves' partial sums in wave order
+        double sum = part[(0 * 16 + lane) * 32 + j];
+#pragma unroll
+        for (int w = 1; w < kSmallWaves; ++w) sum += part[(w * 16 + lane) * 32 + j];
+        m[j] = sum;
+    }
     eigen_denorm_cell<kUseInverseIteration>(m, s_denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
                                             cell < cells ? H + (size_t)cell * 9 : nullptr);
 #ifdef APAP_TRACE_SMALL
@@ -2110,10 +2126,10 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
         ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);   // reported under the K1 slot; the K2 slot stays empty
         const dim3 grid((cells + 15) / 16, 1, batch);
         if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)
-            hipLaunchKernelGGL(k_solve_small<false>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
+            hipLaunchKernelGGL(k_solve_small<false>, grid, dim3(kSmallThreads), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
                                d_denorms, pick_rank, careful, d_H, bs);
         else
-            hipLaunchKernelGGL(k_solve_small<true>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
+            hipLaunchKernelGGL(k_solve_small<true>, grid, dim3(kSmallThreads), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
                                d_denorms, pick_rank, careful, d_H, bs);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
