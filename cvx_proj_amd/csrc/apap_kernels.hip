@@ -847,6 +847,8 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
     bool done = false;
     double vMv = 1.0;  // v^T M^-1 v of the last step: 1 / vMv >= lambda_min (Rayleigh quotient of M^-1)
     below = -1;
+    // (fully unrolled by the compiler; a rolled loop - one copy of the body in the instruction cache - was measured:
+    // no faster, and the guard at it == 2 then no longer interleaves with the third solve)
     for (int it = 0; it < kMaxInvIt; ++it) {
         if (it == 2) below = count_eigs_below(m, rcp_full(vMv) + gap_tol);
         double y[9];
@@ -1356,17 +1358,32 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
             __syncthreads();
         }
     }
-    // cross-wave reduction through LDS (the chunk buffers are free now): part[wave][cell][32 moments].
+    // cross-wave reduction through LDS (the chunk buffers are free now): part[wave][cell][32 moments], rows padded
+    // to 33 doubles so that both "32 moments of a cell" and "one moment of 16 cells" are conflict-free (with 32, the
+    // tail's 16 lanes read 256 B apart: one bank, 16 turns per read).  All threads add the waves' partial sums (in
+    // wave order: the same sums whoever adds them); the tail only picks up its cell's 30 totals.
     // D layout: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15] = (cell, moment)
+    constexpr int kRow = 33;
     double *part = reinterpret_cast<double *>(&lds[0][0]);
+    double *tot = part + kSmallWaves * 16 * kRow;
+    static_assert((kSmallWaves + 1) * 16 * kRow * sizeof(double) <= sizeof(lds), "reduction buffers fit the chunk ring");
 #ifdef APAP_TRACE_SMALL
     tr[2] = clock64();
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ci = kgrp + 4 * i;
-        part[(wave * 16 + ci) * 32 + col] = acc0[i];
-        part[(wave * 16 + ci) * 32 + 16 + col] = acc1[i];
+        part[(wave * 16 + ci) * kRow + col] = acc0[i];
+        part[(wave * 16 + ci) * kRow + 16 + col] = acc1[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = tid; e < 16 * 32; e += kSmallThreads) {
+        const int ce = e >> 5, mo = e & 31;
+        double sum = part[(0 * 16 + ce) * kRow + mo];
+#pragma unroll
+        for (int w = 1; w < kSmallWaves; ++w) sum += part[(w * 16 + ce) * kRow + mo];
+        tot[ce * kRow + mo] = sum;
     }
     __syncthreads();
     if (wave != 0 || lane >= 16) return;       // lanes 0..15 of wave 0 = the block's 16 cells
@@ -1375,12 +1392,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
 #endif
     double m[kMoments];
 #pragma unroll
-    for (int j = 0; j < kMoments; ++j) {   // the waves' partial sums in wave order
-        double sum = part[(0 * 16 + lane) * 32 + j];
-#pragma unroll
-        for (int w = 1; w < kSmallWaves; ++w) sum += part[(w * 16 + lane) * 32 + j];
-        m[j] = sum;
-    }
+    for (int j = 0; j < kMoments; ++j) m[j] = tot[lane * kRow + j];
     eigen_denorm_cell<kUseInverseIteration>(m, s_denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
                                             cell < cells ? H + (size_t)cell * 9 : nullptr);
 #ifdef APAP_TRACE_SMALL

@@ -47,8 +47,9 @@ def random_case(seed):
 
 # 6607, 16739: cells where the reference's float64 SVD is 1.1e-4 ... 2.9e-4 px from the exact answer and the
 # engine equals it; 22280: one float32 value of 5994 differs by one unit in the last place, 8e-4 px at a
-# perspective gain of 14 (found by tools/long_fuzz.py over seeds 40 ... 29 000)
-@pytest.mark.parametrize("seed", list(range(40)) + [6607, 16739, 22280])
+# perspective gain of 14; 36454, 37141: one nearly singular cell each whose float32 INVERSE differs by one ulp
+# (found by tools/long_fuzz.py over seeds 40 ... 42 000)
+@pytest.mark.parametrize("seed", list(range(40)) + [6607, 16739, 22280, 36454, 37141])
 def test_fuzz_solve_and_warp(native, seed):
     c = random_case(1000 + seed)
     H, W = native.local_homography(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"])
@@ -96,7 +97,15 @@ def test_fuzz_solve_and_warp(native, seed):
     good = np.where((np.abs(dets) > 1e-12)[..., None, None], good, np.eye(3, dtype=np.float32)).astype(np.float32)
     out, hinv = native.local_warp(c["img"], good, c["mesh"][0], c["mesh"][1], fw, fh, ox, oy)
     hinv_ref = np.linalg.inv(good.astype(np.float64)).astype(np.float32)
-    assert np.array_equal(hinv, hinv_ref)
+    # numpy inverts a float32 3 x 3 in float64 and rounds (LAPACK dgesv); so does k_warp_setup, with its own
+    # elimination order: the two float64 inverses differ by ~eps * cond, which the float32 rounding hides unless
+    # the matrix is nearly singular (soak seeds 36454 / 37141: one cell each, cond 2e11 / 1e8, one unit in the
+    # last place).  Equality is required below cond 1e6, one float32 ulp per 1e7 of cond above; the warp is
+    # then checked against the oracle run on the engine's own inverses.
+    cond_h = np.linalg.cond(good.astype(np.float64))
+    ulps = ulp_diff_f32(hinv, hinv_ref).reshape(cond_h.shape + (9,)).max(axis=-1)
+    assert (ulps <= np.where(cond_h < 1e6, 0, 1 + cond_h / 1e7)).all(), f"seed {seed}: inverse off by {int(ulps.max())} ulp"
+    hinv_ref = np.where((ulps > 0)[..., None, None], hinv, hinv_ref)
     ref = O.local_warp_fast(c["img"], hinv_ref, c["mesh"], (fw, fh), (ox, oy))
     diff = (out != ref).any(axis=-1)
     if diff.any():

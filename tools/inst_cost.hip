@@ -34,6 +34,22 @@
 #define I_RNDNE(k) "v_rndne_f64 %" #k ", %" #k "\n"
 #define I_LDEXP(k) "v_ldexp_f64 %" #k ", %" #k ", %9\n"
 KERNEL_D(k_fma, I_FMA)
+// dependent chains: every instruction reads the result of the one before it (what K2's tail, one wave per SIMD, is made of)
+#define I_FMA_DEP(k) "v_fma_f64 %0, %0, %8, %8\n"
+#define I_RCP_DEP(k) "v_rcp_f64 %0, %0\n"
+#define I_FMA_DEP2(k) "v_fma_f64 %" #k ", %" #k ", %8, %8\n"  /* used with k & 1: two interleaved chains */
+KERNEL_D(k_fma_dep, I_FMA_DEP)
+KERNEL_D(k_rcp_dep, I_RCP_DEP)
+__global__ __launch_bounds__(256) void k_fma_dep2(double *out, int iters, double a, double b) {
+    double x0 = a + threadIdx.x, x1 = a * 2;
+    for (int it = 0; it < iters; ++it) {
+        REP8(asm volatile("v_fma_f64 %0, %0, %2, %2\nv_fma_f64 %1, %1, %2, %2\nv_fma_f64 %0, %0, %2, %2\nv_fma_f64 %1, %1, %2, %2\n"
+                          "v_fma_f64 %0, %0, %2, %2\nv_fma_f64 %1, %1, %2, %2\nv_fma_f64 %0, %0, %2, %2\nv_fma_f64 %1, %1, %2, %2\n"
+                          : "+v"(x0), "+v"(x1)
+                          : "v"(b));)
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1;
+}
 KERNEL_D(k_mul, I_MUL)
 KERNEL_D(k_add, I_ADD)
 KERNEL_D(k_max, I_MAX)
@@ -102,13 +118,14 @@ int main() {
     struct {
         const char *name;
         kern_t k;
-    } list[] = {{"v_fma_f64", k_fma},     {"v_mul_f64", k_mul},         {"v_add_f64", k_add},         {"v_max_f64", k_max},
+    } list[] = {{"v_fma_f64", k_fma},     {"v_fma_f64 chain", k_fma_dep}, {"v_fma_f64 2 chains", k_fma_dep2}, {"v_rcp_f64 chain", k_rcp_dep},
+                {"v_mul_f64", k_mul},         {"v_add_f64", k_add},         {"v_max_f64", k_max},
                 {"v_rsq_f64", k_rsq},     {"v_rcp_f64", k_rcp},         {"v_sqrt_f64", k_sqrt},       {"v_rndne_f64", k_rndne},
                 {"v_ldexp_f64", k_ldexp}, {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32},
                 {"v_fma_f32", k_fma32},   {"v_add_u32", k_addu32},      {"v_xor_b32", k_xor},         {"v_exp_f32", k_exp32},
                 {"v_rsq_f32", k_rsq32}};
     const int iters = 2000;
-    printf("%-16s %14s %14s   (ns per wave-instruction per SIMD; cycles at 2.4 GHz)\n", "instruction", "8 waves/SIMD",
+    printf("%-20s %14s %14s   (ns per wave-instruction per SIMD; cycles at 2.4 GHz)\n", "instruction", "8 waves/SIMD",
            "1 wave/SIMD");
     for (auto &e : list) {
         double res[2];
@@ -129,7 +146,7 @@ int main() {
             const double inst_per_simd = 64.0 * iters * (mode == 0 ? 8 : 1);
             res[mode] = ms * 1e6 / inst_per_simd;
         }
-        printf("%-16s %8.2f ns %5.1f cyc %8.2f ns %5.1f cyc\n", e.name, res[0], res[0] * 2.4, res[1], res[1] * 2.4);
+        printf("%-20s %8.2f ns %5.1f cyc %8.2f ns %5.1f cyc\n", e.name, res[0], res[0] * 2.4, res[1], res[1] * 2.4);
     }
     (void)hipFree(out);
     return 0;
