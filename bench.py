@@ -571,7 +571,7 @@ def main():
                 "ms_per_call": t_ransac / a.steps * 1e3, "hypotheses": N.RANSAC_ITERATIONS, "points": res.n,
                 "inliers": int(res.r_res.cpu()[1]),
                 "note": "device half of the seed homography (4-point hypotheses, 5 px), baseline_stitch_test.py:42; "
-                        "three small kernels, launch-latency-bound; extra, not in `value`"},
+                        "three small latency-bound kernels; extra, not in `value`"},
             "kernels_ms": kern,
             "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
