@@ -878,18 +878,22 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
         }
         const double scale = copysign(rsqrt_full(nrm2), dot);
         vMv = fabs(dot);
+        // The first two solves cannot have converged (from the uniform start the vector still moves by ~1e-5 in
+        // the second): no convergence test there - the loop is fully unrolled, `it` is a constant in each copy.
         double change = 0.0;
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const double yn = y[i] * scale;
-            change = fmax(change, fabs(yn - v[i]));
+            if (it >= 2) change = fmax(change, fabs(yn - v[i]));
             v[i] = yn;
         }
-        done = change <= 1e-14;  // false for NaN; the error left is that times lambda_9 / lambda_8
 #ifdef APAP_TRACE_SMALL
         ++its;
 #endif
-        if (__all(done || !ok)) break;
+        if (it >= 2) {
+            done = change <= 1e-14;  // false for NaN; the error left is that times lambda_9 / lambda_8
+            if (__all(done || !ok)) break;
+        }
     }
 #ifdef APAP_TRACE_SMALL
     APAP_STAMP(9);
