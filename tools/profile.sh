@@ -13,7 +13,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 # 2. PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-cells --no-call-level --steps 3 --warmup 1 "$@" > /dev/null 2> "$OUT/pmc_$N.err" || { echo "pmc pass $C failed"; tail -3 "$OUT/pmc_$N.err"; }
+  timeout -k 10 200 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-cells --no-call-level --steps 3 --warmup 1 --condition-ms 0 "$@" > /dev/null 2> "$OUT/pmc_$N.err" || { echo "pmc pass $C failed"; tail -3 "$OUT/pmc_$N.err"; }
 done
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
+# the traces hold one line per launch (tens of thousands with the bench's clock conditioning): keep the summaries only
+find "$OUT" -name "*_kernel_trace.csv" -delete -o -name "*_counter_collection.csv" -delete
 cat "$OUT/summary.txt"
