@@ -1537,6 +1537,138 @@ __global__ __launch_bounds__(256) void k_cell_lut(const double *__restrict__ mes
 // search per index.  Valid for any edge order, like the reference's np.where scan.
 constexpr int kMaxEdges = 4096;  // per axis; larger meshes take the linear-scan kernel
 
+// ---- K3 fast path: float32 estimate + doubt window (k_warp_fast below) -------------------------
+// What decides a canvas pixel is int(tx), int(ty) and the strict test 0 < t < size (apap.py:211-215),
+// not the bits of the float64 coordinates.  k_warp_fast therefore works on a float32 ESTIMATE of the
+// coordinates relative to an integer anchor and takes the exact float64 sequence (target_from) only
+// for pixels whose estimate lies within a proven error bound of an integer.
+//
+// Per mesh cell the set-up kernel picks an anchor pixel (xb, yb) = the cell's first canvas column and
+// row, and with h = the cell's stored inverse, t_i(x, y) = h[3i] x + h[3i+1] y + h[3i+2] (real
+// arithmetic), Q = fl(t0(xb, yb) / t2(xb, yb)), n0 = floor(Q), f0 = Q - n0:
+//     tx - n0 = f0 + (R + A dx + B dy) / t2(xb + dx, yb + dy),   A = h0 - Q h6,  B = h1 - Q h7,
+// R = t0b - Q t2b a rounding residual.  The kernel evaluates, in float32 with exactly two FMAs per
+// sum, one v_rcp_f32 and one multiply,
+//     s = (c' + a' dx + b' dy) / (t2b + h6 dx + h7 dy),   a' = A + f h6, b' = B + f h7, c' = f t2b,
+// with f = f0 + dE: the estimate of tx - n0 shifted up by dE, everything scaled by 2^22 so that
+// int(s) is a 10.22 fixed-point number.  With E >= |error of s| + |tx_ref - tx| (bounded below from
+// the magnitudes of this cell; tx_ref = what the reference's float64 sequence returns) and
+// dE = d 2^-22, d = ceil(E 2^22) + 2:  if the low 22 bits of int(s) are >= 2d, then
+// n0 + (int(s) >> 22) < tx_ref < n0 + (int(s) >> 22) + 1 strictly - the truncation, and both strict
+// range tests, follow from the integer alone.  Otherwise the pixel is "in doubt" and is recomputed
+// exactly.  Cells where the bound cannot be established (perspective denominators that change sign or
+// by more than a quarter across the cell, coordinates beyond 2^30, cells wider than 254 pixels, mesh
+// edges that are not increasing) get a record whose window covers everything: correctness never
+// depends on the estimate.
+constexpr int kFastFracBits = 22;
+constexpr int kFastMaxSpan = 254;   // dx, dy travel as bytes
+
+// anchor of cell index c along one axis: first pixel at or after its lower edge, and how many pixels
+// the cell spans (clamped to kFastMaxSpan); false when the edges do not describe an ordinary cell
+__device__ __forceinline__ bool fast_origin(const double *__restrict__ edges, int n_e, int c, int count, int &x0, int &span) {
+    x0 = 0;
+    span = 1;
+    if (c < 0 || c + 1 >= n_e) return false;
+    const double e0 = edges[c], e1 = edges[c + 1];
+    if (!(e0 > -1.0) || !(e1 > e0) || !(e0 < 2147483000.0)) return false;   // NaN fails every test
+    const double a = fmin(fmax(ceil(e0), 0.0), (double)count);
+    const double b = fmin(fmax(ceil(e1), 0.0), (double)count);
+    if (!(b > a)) return false;          // no pixel of the canvas lies in this cell
+    x0 = (int)a;
+    span = (int)fmin(b - a, (double)kFastMaxSpan);
+    return true;
+}
+
+// the 12-dword record k_warp_fast reads per cell: {a'x, b'x, c'x, a'y | b'y, c'y, t2b, h6 | h7, n0x, n0y, thr}
+__device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok, double xb, double yb, double DX,
+                                            double DY, float4 *__restrict__ out) {
+    const double eps64 = 1.1102230246251565e-16, eps32 = 5.9604644775390625e-08, unit = 4194304.0;   // 2^22
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
+    pc.w = __uint_as_float(0xffffffffu);   // window = everything: den = 0 -> s = NaN -> int(s) = 0 < thr
+    const double t0b = fma(h[1], yb, h[0] * xb) + h[2];
+    const double t1b = fma(h[4], yb, h[3] * xb) + h[5];
+    const double t2b = fma(h[7], yb, h[6] * xb) + h[8];
+    // sums of magnitudes over the cell: what the float64 roundings of the reference scale with
+    const double S0 = fabs(h[0]) * (fabs(xb) + DX) + fabs(h[1]) * (fabs(yb) + DY) + fabs(h[2]);
+    const double S1 = fabs(h[3]) * (fabs(xb) + DX) + fabs(h[4]) * (fabs(yb) + DY) + fabs(h[5]);
+    const double S2 = fabs(h[6]) * (fabs(xb) + DX) + fabs(h[7]) * (fabs(yb) + DY) + fabs(h[8]);
+    const double at2 = fabs(t2b);
+    const double g = fabs(h[6]) * DX + fabs(h[7]) * DY;      // how far t2 moves inside the cell
+    bool ok = origin_ok && at2 > 1e-20 && at2 < 1e20 && g <= 0.25 * at2;
+    const double tmin = at2 - g, rho = (at2 + g) / tmin;
+    const double Qx = t0b / t2b, Qy = t1b / t2b;
+    ok = ok && fabs(Qx) < 1073741824.0 && fabs(Qy) < 1073741824.0;
+    const double n0x = floor(Qx), n0y = floor(Qy);
+    const double Ax = fma(-Qx, h[6], h[0]), Bx = fma(-Qx, h[7], h[1]);
+    const double Ay = fma(-Qy, h[6], h[3]), By = fma(-Qy, h[7], h[4]);
+    // |s| / 2^22 <= (|c'| + |a'| DX + |b'| DY) / tmin <= M + f (at2 + g) / tmin,  f < 1.25
+    const double Mx = (fabs(Ax) * DX + fabs(Bx) * DY) / tmin, My = (fabs(Ay) * DX + fabs(By) * DY) / tmin;
+    const double Smax = fmax(Mx, My) + 1.25 * rho;
+    ok = ok && Smax < 500.0;
+    // float32 side, relative to |s|: 3 (inputs + two FMA roundings of the numerator) + 3 rho (the same of
+    // the denominator) + 2 (v_rcp_f32, 1 ulp) + 1 (the product); 0.5 on top for second-order terms
+    const double E32 = (6.5 + 3.0 * rho) * eps32 * Smax;
+    // float64 side: the reference's own roundings of t0, t2 and of the quotient, the residual R of Q,
+    // the roundings of A, B - all <= 16 eps64 (S + (|Q| + Smax)(S2 + |t2b|)) / tmin
+    const double E64 = 16.0 * eps64 * (fmax(S0, S1) + (fmax(fabs(Qx), fabs(Qy)) + Smax) * (S2 + at2)) / tmin;
+    const double du = ceil((E32 + E64) * unit) + 2.0;
+    ok = ok && du < 524288.0;            // dE < 1/8; (2 du) << 10 fits 32 bits
+    if (ok) {
+        const double dE = du / unit;
+        const double fx = (Qx - n0x) + dE, fy = (Qy - n0y) + dE;
+        pa.x = (float)(unit * fma(fx, h[6], Ax));
+        pa.y = (float)(unit * fma(fx, h[7], Bx));
+        pa.z = (float)(unit * (fx * t2b));
+        pa.w = (float)(unit * fma(fy, h[6], Ay));
+        pb.x = (float)(unit * fma(fy, h[7], By));
+        pb.y = (float)(unit * (fy * t2b));
+        pb.z = (float)t2b;
+        pb.w = (float)h[6];
+        pc.x = (float)h[7];
+        pc.y = __int_as_float((int)n0x);
+        pc.z = __int_as_float((int)n0y);
+        pc.w = __uint_as_float(((unsigned)du * 2u) << (32 - kFastFracBits));
+    }
+    out[0] = pa;
+    out[1] = pb;
+    out[2] = pc;
+}
+
+// Workspace of the warp, in this order (every part rounded up to 256 bytes):
+//   hinv_pad [cells][10] f64 | lut [final_h + final_w] i32 | frec [(rows + 1)(cols + 1)][3] float4 |
+//   fcol [final_w rounded up to 4] u32 | frow [final_h] uint2
+// frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
+// `cols` hold the everything-in-doubt record; fcol[j] = cell column | dx << 16, frow[i] = {cell row,
+// float bits of dy}; pixels that are not at 0 <= d < span of an ordinary cell point at the extra row / column.
+struct WarpWork {
+    double *hinv_pad;
+    int *lut;
+    float4 *frec;
+    unsigned *fcol;
+    uint2 *frow;
+    size_t bytes;
+};
+
+__host__ __device__ inline size_t round256(size_t b) { return (b + 255) / 256 * 256; }
+
+inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int final_w, int final_h) {
+    WarpWork w;
+    char *p = (char *)base;
+    const size_t cells = (size_t)mesh_rows * mesh_cols;
+    w.hinv_pad = (double *)p;
+    p += round256(cells * APAP_HINV_STRIDE * sizeof(double));
+    w.lut = (int *)p;
+    p += round256(((size_t)final_w + final_h) * sizeof(int));
+    w.frec = (float4 *)p;
+    p += round256(((size_t)mesh_rows + 1) * ((size_t)mesh_cols + 1) * 3 * sizeof(float4));
+    w.fcol = (unsigned *)p;
+    p += round256((((size_t)final_w + 3) / 4 * 4) * sizeof(unsigned));
+    w.frow = (uint2 *)p;
+    p += round256((size_t)final_h * sizeof(uint2));
+    w.bytes = (size_t)(p - (char *)base);
+    return w;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int cells,
                                                     double *__restrict__ hinv_pad,
@@ -1544,24 +1676,54 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
                                                     const double *__restrict__ mesh_w, int n_w,
                                                     const double *__restrict__ mesh_h, int n_h,
                                                     int mesh_rows, int mesh_cols, int final_w, int final_h,
-                                                    int *__restrict__ lut, int *status) {
+                                                    int *__restrict__ lut, int *status, int off_x, int off_y,
+                                                    float4 *__restrict__ frec, unsigned *__restrict__ fcol,
+                                                    uint2 *__restrict__ frow) {
     __shared__ double pm[2][kMaxEdges];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < inv_blocks) {
-        const int cell = blockIdx.x * 256 + tid;
-        if (cell >= cells) return;
+        // 128 entries of the (rows + 1) x (cols + 1) record table per block (the extra row and column are the
+        // everything-in-doubt records).  Waves 0-1 invert the cells and store the inverses; waves 2-3 invert the
+        // SAME cells again and turn the inverse into the fast record: two short dependent chains side by side
+        // on different SIMDs instead of one long one (the kernel is one wave per SIMD: its time is its chain).
+        const int e = blockIdx.x * 128 + (tid & 127);
+        const bool record_role = tid >= 128;
+        const int er = e / (mesh_cols + 1), ec = e - er * (mesh_cols + 1);
+        if (er > mesh_rows) return;
+        if (er == mesh_rows || ec == mesh_cols) {
+            if (record_role) {
+                const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                fast_record(z, false, 0.0, 0.0, 1.0, 1.0, frec + (size_t)e * 3);
+            }
+            return;
+        }
+        const int cell = er * mesh_cols + ec;
         double m[9], r[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
-        if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
-        double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+        int x0 = 0, y0 = 0, sx = 1, sy = 1;
+        bool okx = false, oky = false;
+        if (record_role) {      // wave-uniform; the edge loads travel with the matrix loads
+            okx = fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
+            oky = fast_origin(mesh_h, n_h, er, final_h, y0, sy);
+        }
+        const bool regular = inv3(m, r);
         // the inverse rounded to the grid's dtype (what the reference stores back, apap.py:203),
         // widened once here instead of nine v_cvt_f64_f32 per pixel in the warp kernel
-        p[0] = make_double2((double)(T)r[0], (double)(T)r[1]);
-        p[1] = make_double2((double)(T)r[2], (double)(T)r[3]);
-        p[2] = make_double2((double)(T)r[4], (double)(T)r[5]);
-        p[3] = make_double2((double)(T)r[6], (double)(T)r[7]);
-        p[4] = make_double2((double)(T)r[8], 0.0);
+        double hd[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hd[k] = (double)(T)r[k];
+        if (record_role) {
+            fast_record(hd, okx && oky, (double)(x0 - off_x), (double)(y0 - off_y), (double)sx, (double)sy, frec + (size_t)e * 3);
+            return;
+        }
+        if (!regular) atomicOr(status, apap::kStatusSingular);
+        double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+        p[0] = make_double2(hd[0], hd[1]);
+        p[1] = make_double2(hd[2], hd[3]);
+        p[2] = make_double2(hd[4], hd[5]);
+        p[3] = make_double2(hd[6], hd[7]);
+        p[4] = make_double2(hd[8], 0.0);
         if (hinv_dense) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
@@ -1604,6 +1766,21 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         bad = bad || c < 0 || c >= ncell;
         if (bad) { atomicOr(status, apap::kStatusIndex); c = 0; }
         lut[(is_row ? 0 : final_h) + idx] = c;
+        // the fast kernel's entry: cell and distance from the cell's anchor, or the extra cell
+        int x0 = 0, span = 1;
+        const bool ok = !bad && fast_origin(edges, n_e, c, count, x0, span);
+        const int d = idx - x0;
+        const bool in = ok && d >= 0 && d < span;
+        const unsigned fc = in ? (unsigned)c : (unsigned)ncell, fd = in ? (unsigned)d : 0u;
+        if (is_row) {
+            frow[idx] = make_uint2(fc, __float_as_uint((float)fd));
+        } else {
+            fcol[idx] = fc | (fd << 16);
+            // the pad up to a multiple of 4 columns repeats the last column (pixels past the row end are
+            // computed like the last one and not stored)
+            if (idx == count - 1)
+                for (int q = idx + 1; q < (count + 3) / 4 * 4; ++q) fcol[q] = fc | (fd << 16);
+        }
     }
 }
 
@@ -1928,6 +2105,228 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
     }
 }
 
+// K3, default form: the row strips of k_warp_rows with the float32 estimate described at fast_record.
+// Same unit of work (a lane owns 4 consecutive pixels of a canvas row and walks kRows rows with them),
+// same gathers and stores; what differs is how a pixel's source offset is found:
+//   * the lane's four column entries arrive in ONE 16-byte load (cell column | dx << 16), the strip's
+//     row entries by scalar loads ({cell row, dy as float}: the rows are wave-uniform);
+//   * per cell row the strip touches, two 48-byte records (first and last pixel's cells) instead of two
+//     80-byte matrices; per pixel and row 3 float32 FMAs, one v_rcp_f32, two products, two conversions
+//     and integer work - no float64 instruction at all;
+//   * a pixel whose fixed-point estimate has its low 22 bits inside the cell's doubt window (a few in
+//     10^5 on BASELINE's configurations) is recomputed with the exact float64 sequence - the same code
+//     k_warp_rows runs for every pixel - in a loop that only waves holding such a pixel enter.
+// 40 instead of 72 registers of per-pixel constants, 6-8 waves per SIMD instead of 4.
+// the 3 bytes at byte offset `o` of the source as a 24-bit value; 0 for the "outside" marker 0xffffffff.
+// Reads the dword at the pixel's first byte; for the image's very last pixel the dword one byte earlier,
+// shifted (v_alignbyte_b32), so that no byte beyond the image is touched.
+__device__ __forceinline__ unsigned gather_px(const uint8_t *__restrict__ img, unsigned o, unsigned last) {
+    unsigned int v;
+    const unsigned oc = o < last ? o : last;
+#ifdef APAP_K3_ABL_NOGATHER
+    v = oc;
+#else
+    __builtin_memcpy(&v, img + oc, 4);
+#endif
+    v = __builtin_amdgcn_alignbyte(0u, v, o - oc);
+    // v & 0xffffff & ~sign(o): v_bfe_i32 + v_bitop3_b32 (truth table a & b & ~c = 0x40)
+    return (unsigned)__builtin_amdgcn_bitop3_b32((int)v, 0x00ffffff, __builtin_amdgcn_sbfe((int)o, 31u, 1u), 0x40);
+}
+
+__device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv_pad, const int *__restrict__ lut, int mesh_cols,
+                                                 int final_h, int i, int j, int off_x, int off_y, int img_w, int img_h) {
+    const int cell = lut[(unsigned)i] * mesh_cols + lut[(unsigned)(final_h + j)];
+    double tx, ty;
+    target_of(hinv_pad, cell, (double)(j - off_x), (double)(i - off_y), tx, ty);
+    const int ix = (int)tx, iy = (int)ty;
+    const bool ok = (tx > 0.0) & (ty > 0.0) & (ix < img_w) & (iy < img_h);   // as in k_warp_rows
+    return ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
+}
+
+template <bool kBlend, int kRows>
+__global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
+                                                   const double *__restrict__ hinv_pad, int mesh_cols,
+                                                   const int *__restrict__ lut, const float4 *__restrict__ frec,
+                                                   const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
+                                                   int final_w, int final_h, int off_x, int off_y,
+                                                   uint8_t *__restrict__ out, const uint8_t *__restrict__ center,
+                                                   int center_h, int center_w, int row_begin, int row_count) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
+    const int y_first = row_begin + ((int)blockIdx.y * 4 + wave) * kRows;
+    const int y_end = min(y_first + kRows, row_begin + row_count);
+    if (j0 >= final_w || y_first >= y_end) return;
+    const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
+    const unsigned clast = kBlend ? (unsigned)center_h * (unsigned)center_w * 3u - 4u : 0u;
+    const int npx = min(4, final_w - j0);
+    // column entries of the lane's four pixels (the table is padded to a multiple of 4 columns)
+    const uint4 ce = *reinterpret_cast<const uint4 *>(fcol + j0);
+    const unsigned cev[4] = {ce.x, ce.y, ce.z, ce.w};
+    unsigned col[4];
+    float dxf[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        col[k] = cev[k] & 0xffffu;
+        dxf[k] = (float)((cev[k] >> 16) & 0xffu);    // v_cvt_f32_ubyte2
+    }
+    // row entries: wave-uniform, scalar loads
+    unsigned rr[kRows];
+    float dyf[kRows];
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) {
+        const uint2 e = frow[(unsigned)min(y_first + t, y_end - 1)];
+        rr[t] = __builtin_amdgcn_readfirstlane(e.x);
+        dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.y));
+    }
+    unsigned off[kRows][4];
+    unsigned int px[kRows][4];
+    unsigned long long doubt[kRows][4];    // lane masks (scalar registers)
+    const unsigned rec_stride = (unsigned)(mesh_cols + 1);
+    unsigned todo = (1u << kRows) - 1u;
+#ifdef APAP_K3_ABL_COPY   // experiment: no coordinate work at all - the access pattern's own floor
+    todo = 0u;
+#pragma unroll
+    for (int t = 0; t < kRows; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            doubt[t][k] = 0;
+            off[t][k] = (__umul24((unsigned)min(y_first + t, img_h - 1), (unsigned)img_w) + (unsigned)min(j0 + k, img_w - 1)) * 3u;
+        }
+#endif
+    while (todo != 0u) {    // one pass per cell row the strip touches; wave-uniform
+        const int first = __builtin_ctz(todo);
+        unsigned r = rr[0];
+#pragma unroll
+        for (int t = 1; t < kRows; ++t) r = (t == first) ? rr[t] : r;
+        const unsigned base = r * rec_stride;
+        const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
+        const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        // per pixel: x-dependent parts of the three sums, the y coefficients, anchor, window
+        float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
+        int n0x[4], n0y[4];
+        unsigned thr[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool is_a = (k == 0) || (k != 3 && col[k] == col[0]);
+            const float4 q0 = is_a ? a0 : b0, q1 = is_a ? a1 : b1, q2 = is_a ? a2 : b2;
+            nx0[k] = __builtin_fmaf(q0.x, dxf[k], q0.z);
+            ny0[k] = __builtin_fmaf(q0.w, dxf[k], q1.y);
+            dn0[k] = __builtin_fmaf(q1.w, dxf[k], q1.z);
+            bx[k] = q0.y; by[k] = q1.x; h7[k] = q2.x;
+            n0x[k] = __float_as_int(q2.y); n0y[k] = __float_as_int(q2.z);
+            thr[k] = __float_as_uint(q2.w);
+            // a third cell inside four pixels (cells narrower than the group): exact path
+            if (k == 1 || k == 2) thr[k] = (!is_a && col[k] != col[3]) ? 0xffffffffu : thr[k];
+        }
+#pragma unroll
+        for (int t = 0; t < kRows; ++t) {
+            if (rr[t] != r) continue;
+            todo &= ~(1u << t);
+            const float dy = dyf[t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float num_x = __builtin_fmaf(bx[k], dy, nx0[k]);
+                const float num_y = __builtin_fmaf(by[k], dy, ny0[k]);
+                const float den = __builtin_fmaf(h7[k], dy, dn0[k]);
+                const float rc = __builtin_amdgcn_rcpf(den);
+                const int fx = (int)(num_x * rc), fy = (int)(num_y * rc);      // 10.22 fixed point; NaN -> 0
+                const int ix = n0x[k] + (fx >> kFastFracBits), iy = n0y[k] + (fy >> kFastFracBits);
+                const unsigned lo = min((unsigned)fx << (32 - kFastFracBits), (unsigned)fy << (32 - kFastFracBits));
+                doubt[t][k] = __builtin_amdgcn_ballot_w64(lo < thr[k]);
+                const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
+                off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
+            }
+#ifndef APAP_K3_LATE_GATHER
+            // the row's four gathers go out now: their latency runs under the next rows' arithmetic
+#pragma unroll
+            for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
+#endif
+        }
+    }
+    // pixels in doubt: the exact float64 sequence.  Only waves that hold one come here.
+    {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int t = 0; t < kRows; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) any |= doubt[t][k];
+        if (any != 0) {
+            unsigned bits = 0;
+#pragma unroll
+            for (int t = 0; t < kRows; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) bits |= ((doubt[t][k] >> lane) & 1ull) ? (1u << (t * 4 + k)) : 0u;
+            while (bits != 0u) {
+                const int idx = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                const int i = min(y_first + (idx >> 2), y_end - 1), j = min(j0 + (idx & 3), final_w - 1);
+                const unsigned o = exact_offset(hinv_pad, lut, mesh_cols, final_h, i, j, off_x, off_y, img_w, img_h);
+#ifndef APAP_K3_LATE_GATHER
+                const unsigned v = gather_px(img, o, last);
+#pragma unroll
+                for (int t = 0; t < kRows; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) px[t][k] = (idx == t * 4 + k) ? v : px[t][k];
+#else
+#pragma unroll
+                for (int t = 0; t < kRows; ++t)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) off[t][k] = (idx == t * 4 + k) ? o : off[t][k];
+#endif
+            }
+        }
+    }
+#if defined(APAP_K3_LATE_GATHER) || defined(APAP_K3_ABL_COPY)
+#pragma unroll
+    for (int t = 0; t < kRows; ++t)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
+#endif
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) {
+        const int y = y_first + t;
+        if (y >= y_end) break;  // wave-uniform
+        if (kBlend) {
+            const int ci = y - off_y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cj = j0 + k - off_x;
+                const bool in = ci >= 0 && ci < center_h && cj >= 0 && cj < center_w;
+                const unsigned co = in ? ((unsigned)ci * (unsigned)center_w + (unsigned)cj) * 3u : 0u;
+                const unsigned cc = co < clast ? co : clast;
+                unsigned int c;
+                __builtin_memcpy(&c, center + cc, 4);
+                c = in ? ((c >> (8 * (co - cc))) & 0x00ffffffu) : 0u;
+                const unsigned w = px[t][k];
+                const unsigned avg = (w & c) + (((w ^ c) & 0x00fefefeu) >> 1);
+                px[t][k] = (w != 0u && c != 0u) ? avg : (w | c);
+            }
+        }
+        uint8_t *o = out + ((size_t)(y - row_begin) * (size_t)final_w) * 3 + (unsigned)j0 * 3u;
+#ifdef APAP_K3_ABL_NOSTORE
+        if ((px[t][0] ^ px[t][1] ^ px[t][2] ^ px[t][3]) != 0x12345678u) continue;   // never true for 24-bit pixels
+#endif
+        if (npx == 4) {
+            Bytes12 v;
+            v.a = px[t][0] | (px[t][1] << 24);
+            v.b = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
+            v.c = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
+#ifdef APAP_K3_NT_STORE
+            __builtin_nontemporal_store(v, reinterpret_cast<Bytes12 *>(o));
+#else
+            __builtin_memcpy(o, &v, 12);
+#endif
+        } else {
+            for (int k = 0; k < npx; ++k) {
+                o[3 * k] = (uint8_t)(px[t][k] & 0xff);
+                o[3 * k + 1] = (uint8_t)((px[t][k] >> 8) & 0xff);
+                o[3 * k + 2] = (uint8_t)((px[t][k] >> 16) & 0xff);
+            }
+        }
+    }
+}
+
 // coordinates only (parity tests of the arithmetic of k_warp)
 __global__ __launch_bounds__(256) void k_warp_coords(const double *__restrict__ hinv_pad, int mesh_cols,
                                                      const int *__restrict__ lut, int final_w,
@@ -2071,6 +2470,7 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 2 || value == 4 || value == 8; break;
         case APAP_OPT_WEIGHT_CHUNK_KB: ok = value >= 1; break;
         case APAP_OPT_FUSED_MAX_CELLS: ok = value >= 0; break;
+        case APAP_OPT_WARP_FAST: ok = value == 0 || value == 1; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
     }
     if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
@@ -2205,9 +2605,7 @@ int apap_weights_device(apap_ctx *ctx, const double *d_table, int n, const doubl
 
 size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h) {
     if (mesh_rows < 1 || mesh_cols < 1 || final_w < 1 || final_h < 1) return 0;
-    const size_t hinv = (size_t)mesh_rows * mesh_cols * APAP_HINV_STRIDE * sizeof(double);
-    const size_t lut = ((size_t)final_w + final_h) * sizeof(int);
-    return ((hinv + 255) / 256) * 256 + ((lut + 255) / 256) * 256;
+    return warp_work_layout(nullptr, mesh_rows, mesh_cols, final_w, final_h).bytes;
 }
 
 }  // extern "C"
@@ -2216,7 +2614,7 @@ template <typename T>
 static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
                          int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
                          T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                         hipStream_t s, double **hinv_pad, int **lut) {
+                         hipStream_t s, int off_x, int off_y, WarpWork *ww, bool *fast_tables) {
     if (!d_Hfwd || !d_mesh_w || !d_mesh_h || !d_work || !d_status)
         return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
     if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
@@ -2224,27 +2622,27 @@ static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh
     const size_t need = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
     if (work_bytes < need) return apap::fail(APAP_ERR_WORKSPACE, "warp: workspace %zu < %zu bytes", work_bytes, need);
     const int cells = mesh_rows * mesh_cols;
-    const size_t hinv_bytes = (((size_t)cells * APAP_HINV_STRIDE * sizeof(double) + 255) / 256) * 256;
-    *hinv_pad = (double *)d_work;
-    *lut = (int *)((char *)d_work + hinv_bytes);
-    if (n_w <= kMaxEdges && n_h <= kMaxEdges) {
-        // one launch: cell inverses + lookup table (reported under the INVERT slot)
+    *ww = warp_work_layout(d_work, mesh_rows, mesh_cols, final_w, final_h);
+    *fast_tables = false;
+    if (n_w <= kMaxEdges && n_h <= kMaxEdges && mesh_rows < 65535 && mesh_cols < 65535) {
+        // one launch: cell inverses + fast records + lookup tables (reported under the INVERT slot)
         ProfScope prof(ctx, APAP_PROF_INVERT, s);
-        const int inv_blocks = (cells + 255) / 256;
+        const int inv_blocks = (int)(((size_t)(mesh_rows + 1) * (mesh_cols + 1) + 127) / 128);   // 128 record-table entries per block
         const int lut_blocks = (final_h + 1023) / 1024 + (final_w + 1023) / 1024;
-        hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+        hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, ww->hinv_pad,
                            d_Hinv_out, inv_blocks, d_mesh_w, n_w, d_mesh_h, n_h, mesh_rows, mesh_cols, final_w,
-                           final_h, *lut, d_status);
+                           final_h, ww->lut, d_status, off_x, off_y, ww->frec, ww->fcol, ww->frow);
+        *fast_tables = true;
     } else {
         {
             ProfScope prof(ctx, APAP_PROF_INVERT, s);
-            hipLaunchKernelGGL(k_invert_cells<T>, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, *hinv_pad,
+            hipLaunchKernelGGL(k_invert_cells<T>, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, ww->hinv_pad,
                                d_Hinv_out, d_status);
         }
         {
             ProfScope prof(ctx, APAP_PROF_LUT, s);
             hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
-                               d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, *lut, d_status);
+                               d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, ww->lut, d_status);
         }
     }
     return APAP_OK;
@@ -2280,11 +2678,13 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
     if ((unsigned long long)mesh_rows * (unsigned long long)mesh_cols * APAP_HINV_STRIDE * sizeof(double) >= (1ull << 32))
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: mesh of 53 million cells or more");
     hipStream_t s = (hipStream_t)stream;
-    double *hinv_pad;
-    int *lut;
+    WarpWork ww;
+    bool fast_tables;
     const int rc = warp_prologue<T>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                    d_Hinv_out, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
+                                    d_Hinv_out, d_work, work_bytes, d_status, s, off_x, off_y, &ww, &fast_tables);
     if (rc != APAP_OK) return rc;
+    double *hinv_pad = ww.hinv_pad;
+    int *lut = ww.lut;
     if (row_count == 0) return APAP_OK;  // an empty band: only the set-up kernel ran
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
@@ -2294,8 +2694,29 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
     const int warp_kernel = apap::opt(ctx, APAP_OPT_WARP_ROWS);
     // the strip kernel forms source offsets with 24-bit multiplies
     // ... and marks pixels outside the source with the sign bit of the byte offset
-    if (warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24) &&
-        (unsigned long long)img_h * (unsigned long long)img_w * 3ull < (1ull << 31)) {
+    const bool strips = warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24) &&
+                        (unsigned long long)img_h * (unsigned long long)img_w * 3ull < (1ull << 31);
+    // APAP_OPT_WARP_FAST (default 1): the float32-estimate kernel.  It is exact for any input, but a pixel the
+    // estimate cannot decide costs a trip through the exact sequence, and every pixel of a cell wider than
+    // 254 pixels is one: meshes that coarse (on average) keep the all-float64 strip kernel.
+    if (strips && fast_tables && apap::opt(ctx, APAP_OPT_WARP_FAST) && final_w / mesh_cols <= 128 && final_h / mesh_rows <= 128) {
+        ProfScope prof(ctx, APAP_PROF_WARP, s);
+        const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;
+        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
+#define APAP_LAUNCH_FAST(R)                                                                                          \
+    if (d_center)                                                                                                    \
+        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols,  \
+                           lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out, d_center,           \
+                           center_h, center_w, row_begin, row_count);                                                \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, \
+                           lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
+                           (const uint8_t *)nullptr, 0, 0, row_begin, row_count)
+        if (rows == 4) { APAP_LAUNCH_FAST(4); }
+        else if (rows == 8) { APAP_LAUNCH_FAST(8); }
+        else { APAP_LAUNCH_FAST(2); }
+#undef APAP_LAUNCH_FAST
+    } else if (strips) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;  // rows per wave: instantiated for 2, 4, 8
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
@@ -2373,11 +2794,13 @@ int apap_warp_coords_device(apap_ctx *ctx, const float *d_Hfwd, int mesh_rows, i
                             int *d_status, void *stream) {
     if (!d_coords) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_coords_device: null output");
     hipStream_t s = (hipStream_t)stream;
-    double *hinv_pad;
-    int *lut;
+    WarpWork ww;
+    bool fast_tables;
     const int rc = warp_prologue<float>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                        nullptr, d_work, work_bytes, d_status, s, &hinv_pad, &lut);
+                                        nullptr, d_work, work_bytes, d_status, s, off_x, off_y, &ww, &fast_tables);
     if (rc != APAP_OK) return rc;
+    double *hinv_pad = ww.hinv_pad;
+    int *lut = ww.lut;
     const size_t total = (size_t)final_w * final_h;
     hipLaunchKernelGGL(k_warp_coords, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, hinv_pad, mesh_cols,
                        lut, final_w, final_h, off_x, off_y, d_coords);

@@ -103,7 +103,10 @@ typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_WEIGHT_CHUNK_KB 6 /* device staging of the optional weight tensor, KiB (default 1 GiB)   */
 #define APAP_OPT_FUSED_MAX_CELLS 7 /* tuning: meshes of up to this many cells (x batch) take the fused K1 + K2
                                       launch when the variant is AUTO (default 4096; 0 = never)             */
-#define APAP_OPT_COUNT 8
+#define APAP_OPT_WARP_FAST 8       /* 1 (default): K3 decides a pixel from a float32 estimate of its source coordinate
+                                      and takes the exact float64 sequence only where the estimate is within its error
+                                      bound of an integer (same canvas, byte for byte); 0: float64 for every pixel    */
+#define APAP_OPT_COUNT 9
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);
