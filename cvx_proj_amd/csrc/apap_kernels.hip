@@ -1638,8 +1638,9 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
 //   hinv_pad [cells][10] f64 | lut [final_h + final_w] i32 | frec [(rows + 1)(cols + 1)][3] float4 |
 //   fcol [final_w rounded up to 4] u32 | frow [final_h] uint2
 // frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
-// `cols` hold the everything-in-doubt record; fcol[j] = cell column | dx << 16, frow[i] = {cell row,
-// float bits of dy}; pixels that are not at 0 <= d < span of an ordinary cell point at the extra row / column.
+// `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row,
+// float bits of dy}, dx / dy = signed distance from the cell's anchor (its middle pixel); pixels that are not
+// inside an ordinary cell point at the extra row / column.
 struct WarpWork {
     double *hinv_pad;
     int *lut;
@@ -1682,43 +1683,31 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
     __shared__ double pm[2][kMaxEdges];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < inv_blocks) {
-        // 128 entries of the (rows + 1) x (cols + 1) record table per block (the extra row and column are the
-        // everything-in-doubt records).  Waves 0-1 invert the cells and store the inverses; waves 2-3 invert the
-        // SAME cells again and turn the inverse into the fast record: two short dependent chains side by side
-        // on different SIMDs instead of one long one (the kernel is one wave per SIMD: its time is its chain).
-        const int e = blockIdx.x * 128 + (tid & 127);
-        const bool record_role = tid >= 128;
+        // one thread per entry of the (rows + 1) x (cols + 1) record table; the extra row and column are the
+        // everything-in-doubt records.  (Inverting each cell twice, in two waves - one storing the inverse, one
+        // building the record - to shorten the dependent chain measured slower: 8.6 vs 7.6 us.)
+        const int e = blockIdx.x * 256 + tid;
         const int er = e / (mesh_cols + 1), ec = e - er * (mesh_cols + 1);
         if (er > mesh_rows) return;
         if (er == mesh_rows || ec == mesh_cols) {
-            if (record_role) {
-                const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                fast_record(z, false, 0.0, 0.0, 1.0, 1.0, frec + (size_t)e * 3);
-            }
+            const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            fast_record(z, false, 0.0, 0.0, 1.0, 1.0, frec + (size_t)e * 3);
             return;
         }
         const int cell = er * mesh_cols + ec;
         double m[9], r[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
-        int x0 = 0, y0 = 0, sx = 1, sy = 1;
-        bool okx = false, oky = false;
-        if (record_role) {      // wave-uniform; the edge loads travel with the matrix loads
-            okx = fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
-            oky = fast_origin(mesh_h, n_h, er, final_h, y0, sy);
-        }
-        const bool regular = inv3(m, r);
+        int x0, y0, sx, sy;      // the edge loads travel with the matrix loads
+        const bool okx = fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
+        const bool oky = fast_origin(mesh_h, n_h, er, final_h, y0, sy);
+        if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
+        double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
         // the inverse rounded to the grid's dtype (what the reference stores back, apap.py:203),
         // widened once here instead of nine v_cvt_f64_f32 per pixel in the warp kernel
         double hd[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) hd[k] = (double)(T)r[k];
-        if (record_role) {
-            fast_record(hd, okx && oky, (double)(x0 - off_x), (double)(y0 - off_y), (double)sx, (double)sy, frec + (size_t)e * 3);
-            return;
-        }
-        if (!regular) atomicOr(status, apap::kStatusSingular);
-        double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
         p[0] = make_double2(hd[0], hd[1]);
         p[1] = make_double2(hd[2], hd[3]);
         p[2] = make_double2(hd[4], hd[5]);
@@ -1728,6 +1717,9 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
 #pragma unroll
             for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
         }
+        // anchor in the middle of the cell: the estimate's error grows with the distance from it
+        fast_record(hd, okx && oky, (double)(x0 + sx / 2 - off_x), (double)(y0 + sy / 2 - off_y), (double)(sx - sx / 2),
+                    (double)(sy - sy / 2), frec + (size_t)e * 3);
         return;
     }
     const int row_blocks = (final_h + 1023) / 1024;
@@ -1771,9 +1763,11 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         const bool ok = !bad && fast_origin(edges, n_e, c, count, x0, span);
         const int d = idx - x0;
         const bool in = ok && d >= 0 && d < span;
-        const unsigned fc = in ? (unsigned)c : (unsigned)ncell, fd = in ? (unsigned)d : 0u;
+        const unsigned fc = in ? (unsigned)c : (unsigned)ncell;
+        const int rel = in ? d - span / 2 : 0;       // distance from the cell's anchor (its middle pixel), -127 ... 127
+        const unsigned fd = (unsigned)(rel + 128);
         if (is_row) {
-            frow[idx] = make_uint2(fc, __float_as_uint((float)fd));
+            frow[idx] = make_uint2(fc, __float_as_uint((float)rel));
         } else {
             fcol[idx] = fc | (fd << 16);
             // the pad up to a multiple of 4 columns repeats the last column (pixels past the row end are
@@ -2133,9 +2127,14 @@ __device__ __forceinline__ unsigned gather_px(const uint8_t *__restrict__ img, u
     return (unsigned)__builtin_amdgcn_bitop3_b32((int)v, 0x00ffffff, __builtin_amdgcn_sbfe((int)o, 31u, 1u), 0x40);
 }
 
-__device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv_pad, const int *__restrict__ lut, int mesh_cols,
-                                                 int final_h, int i, int j, int off_x, int off_y, int img_w, int img_h) {
-    const int cell = lut[(unsigned)i] * mesh_cols + lut[(unsigned)(final_h + j)];
+// `cr`, `cc`: the pixel's cell row and column as the fast tables give them - the exact table's values unless they
+// point at the extra row / column (then the exact table is read: one more memory round trip, irregular meshes only)
+__device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv_pad, const int *__restrict__ lut, int mesh_rows,
+                                                 int mesh_cols, int final_h, unsigned cr, unsigned cc, int i, int j, int off_x,
+                                                 int off_y, int img_w, int img_h) {
+    if (cr >= (unsigned)mesh_rows) cr = (unsigned)lut[(unsigned)i];
+    if (cc >= (unsigned)mesh_cols) cc = (unsigned)lut[(unsigned)(final_h + j)];
+    const int cell = (int)(cr * (unsigned)mesh_cols + cc);
     double tx, ty;
     target_of(hinv_pad, cell, (double)(j - off_x), (double)(i - off_y), tx, ty);
     const int ix = (int)tx, iy = (int)ty;
@@ -2145,7 +2144,7 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
 
 template <bool kBlend, int kRows>
 __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
-                                                   const double *__restrict__ hinv_pad, int mesh_cols,
+                                                   const double *__restrict__ hinv_pad, int mesh_rows, int mesh_cols,
                                                    const int *__restrict__ lut, const float4 *__restrict__ frec,
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
                                                    int final_w, int final_h, int off_x, int off_y,
@@ -2168,7 +2167,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         col[k] = cev[k] & 0xffffu;
-        dxf[k] = (float)((cev[k] >> 16) & 0xffu);    // v_cvt_f32_ubyte2
+        dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
     // row entries: wave-uniform, scalar loads
     unsigned rr[kRows];
@@ -2237,11 +2236,6 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
                 const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
                 off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
             }
-#ifndef APAP_K3_LATE_GATHER
-            // the row's four gathers go out now: their latency runs under the next rows' arithmetic
-#pragma unroll
-            for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
-#endif
         }
     }
     // pixels in doubt: the exact float64 sequence.  Only waves that hold one come here.
@@ -2261,28 +2255,25 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
                 const int idx = __builtin_ctz(bits);
                 bits &= bits - 1u;
                 const int i = min(y_first + (idx >> 2), y_end - 1), j = min(j0 + (idx & 3), final_w - 1);
-                const unsigned o = exact_offset(hinv_pad, lut, mesh_cols, final_h, i, j, off_x, off_y, img_w, img_h);
-#ifndef APAP_K3_LATE_GATHER
-                const unsigned v = gather_px(img, o, last);
+                unsigned cr = rr[0], cc = col[0];
 #pragma unroll
-                for (int t = 0; t < kRows; ++t)
+                for (int t = 1; t < kRows; ++t) cr = (idx >> 2) == t ? rr[t] : cr;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) px[t][k] = (idx == t * 4 + k) ? v : px[t][k];
-#else
+                for (int k = 1; k < 4; ++k) cc = (idx & 3) == k ? col[k] : cc;
+                const unsigned o = exact_offset(hinv_pad, lut, mesh_rows, mesh_cols, final_h, cr, cc, i, j, off_x, off_y, img_w, img_h);
 #pragma unroll
                 for (int t = 0; t < kRows; ++t)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) off[t][k] = (idx == t * 4 + k) ? o : off[t][k];
-#endif
             }
         }
     }
-#if defined(APAP_K3_LATE_GATHER) || defined(APAP_K3_ABL_COPY)
+    // all of the strip's gathers in flight together (issuing a row's as soon as its offsets exist, or dropping
+    // the range tests and the last-pixel guard for waves wholly inside the source, measured no faster: DESIGN.md)
 #pragma unroll
     for (int t = 0; t < kRows; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
-#endif
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const int y = y_first + t;
@@ -2312,11 +2303,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
             v.a = px[t][0] | (px[t][1] << 24);
             v.b = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
             v.c = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
-#ifdef APAP_K3_NT_STORE
-            __builtin_nontemporal_store(v, reinterpret_cast<Bytes12 *>(o));
-#else
             __builtin_memcpy(o, &v, 12);
-#endif
         } else {
             for (int k = 0; k < npx; ++k) {
                 o[3 * k] = (uint8_t)(px[t][k] & 0xff);
@@ -2627,7 +2614,7 @@ static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh
     if (n_w <= kMaxEdges && n_h <= kMaxEdges && mesh_rows < 65535 && mesh_cols < 65535) {
         // one launch: cell inverses + fast records + lookup tables (reported under the INVERT slot)
         ProfScope prof(ctx, APAP_PROF_INVERT, s);
-        const int inv_blocks = (int)(((size_t)(mesh_rows + 1) * (mesh_cols + 1) + 127) / 128);   // 128 record-table entries per block
+        const int inv_blocks = (int)(((size_t)(mesh_rows + 1) * (mesh_cols + 1) + 255) / 256);
         const int lut_blocks = (final_h + 1023) / 1024 + (final_w + 1023) / 1024;
         hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, ww->hinv_pad,
                            d_Hinv_out, inv_blocks, d_mesh_w, n_w, d_mesh_h, n_h, mesh_rows, mesh_cols, final_w,
@@ -2705,11 +2692,11 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
 #define APAP_LAUNCH_FAST(R)                                                                                          \
     if (d_center)                                                                                                    \
-        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols,  \
+        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out, d_center,           \
                            center_h, center_w, row_begin, row_count);                                                \
     else                                                                                                             \
-        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, \
+        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
                            (const uint8_t *)nullptr, 0, 0, row_begin, row_count)
         if (rows == 4) { APAP_LAUNCH_FAST(4); }

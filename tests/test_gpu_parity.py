@@ -813,14 +813,16 @@ def test_batched_solve_equals_separate_solves(native):
         assert torch.equal(H2[k], Hk), k
 
 
-@pytest.mark.parametrize("rows_per_wave", [0, 2, 8])
-def test_other_warp_kernel_forms_still_match(native, golden, rows_per_wave):
-    """The flat-order kernel (0) is the fallback for sources the strip kernel does not take (a side of
-    2^24 pixels, 2 GiB); strips of 2 and 8 rows are the other instantiations.  APAP_OPT_WARP_ROWS of a
-    context selects them: same canvases, byte for byte, as the default and as the reference's -
-    tiny cases, every warp edge case, the fused stitch and a full C2 canvas."""
+@pytest.mark.parametrize("rows_per_wave,fast", [(0, 1), (2, 1), (8, 1), (2, 0), (4, 0), (8, 0)])
+def test_other_warp_kernel_forms_still_match(native, golden, rows_per_wave, fast):
+    """The flat-order kernel (0) is the fallback for sources the strip kernels do not take (a side of
+    2^24 pixels, 2 GiB); strips of 2 and 8 rows are the other instantiations; APAP_OPT_WARP_FAST = 0 is the
+    strip kernel that runs the float64 sequence for every pixel (the default decides from a float32 estimate
+    and falls back to float64 near integer boundaries).  Context options select them: same canvases, byte
+    for byte, as the default and as the reference's - tiny cases, every warp edge case, the fused stitch
+    and a full C2 canvas."""
     import hashlib
-    ctx = native.Context(warp_rows=rows_per_wave)
+    ctx = native.Context(warp_rows=rows_per_wave, warp_fast=fast)
     for name in TINY:
         g = golden(name)
         fw, fh, ox, oy = (int(v) for v in g["final"])
@@ -839,6 +841,61 @@ def test_other_warp_kernel_forms_still_match(native, golden, rows_per_wave):
     w, _ = native.local_warp(p.img, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=ctx)
     assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fast_warp_on_irregular_meshes_and_strong_perspective(native, seed):
+    """The float32-estimate kernel must be exact on ANY input: cells it has no error bound for (edges that are
+    not increasing, repeated edges, cells wider than 254 pixels or narrower than a lane's 4 pixels, perspective
+    denominators that change sign inside a cell, matrices with huge entries) go through its exact path.  Random
+    such inputs: default kernel == all-float64 strip kernel == oracle, byte for byte."""
+    rng = np.random.default_rng(9000 + seed)
+    ih, iw = int(rng.integers(40, 300)), int(rng.integers(40, 700))
+    img = rng.integers(1, 256, (ih, iw, 3), dtype=np.uint8)
+    fw, fh = int(rng.integers(5, 900)), int(rng.integers(5, 260))
+    rows, cols = int(rng.integers(1, 12)), int(rng.integers(1, 40))
+
+    def edges(n, size):
+        e = np.sort(rng.uniform(0, size, n - 2))
+        e = np.concatenate([[0.0], e, [float(size)]])
+        kind = seed % 4
+        if kind == 1 and n > 2:                 # a repeated edge and a pair out of order
+            e[1] = e[2]
+            if n > 4:
+                e[3], e[4] = e[4], e[3]
+        elif kind == 2:                         # integer edges: pixels exactly on a boundary
+            e = np.round(e)
+            e[-1] = size
+        elif kind == 3 and n > 3:               # one very wide cell, several one-pixel cells
+            e[1:4] = [1.0, 2.0, 3.0]
+        return e
+    mesh_w, mesh_h = edges(cols + 1, fw), edges(rows + 1, fh)
+    mesh_w[-1] = max(mesh_w.max(), fw)
+    mesh_h[-1] = max(mesh_h.max(), fh)
+    H = np.empty((rows, cols, 3, 3), np.float32)
+    for r in range(rows):
+        for c in range(cols):
+            a = rng.uniform(-0.4, 0.4)
+            s = np.exp(rng.uniform(-0.5, 0.5))
+            persp = rng.normal(0, 1, 2) * 10.0 ** rng.uniform(-6, -1.5)      # up to sign changes inside the canvas
+            H[r, c] = [[s * np.cos(a), -s * np.sin(a), rng.uniform(-30, 30)],
+                       [s * np.sin(a), s * np.cos(a), rng.uniform(-30, 30)],
+                       [persp[0], persp[1], 1.0]]
+    if seed % 3 == 0:
+        H[0, 0] *= 1e12                          # the same homography, huge entries
+    ox, oy = int(rng.integers(-20, 20)), int(rng.integers(-20, 20))
+    hinv_ref = np.linalg.inv(H.astype(np.float64)).astype(np.float32)
+    ref = O.local_warp_fast(img, hinv_ref, (mesh_w, mesh_h), (fw, fh), (ox, oy))
+    exact_ctx = native.Context(warp_fast=0)
+    try:
+        out_f, hinv_f = native.local_warp(img, H.copy(), mesh_w, mesh_h, fw, fh, ox, oy)
+        out_e, hinv_e = native.local_warp(img, H.copy(), mesh_w, mesh_h, fw, fh, ox, oy, ctx=exact_ctx)
+    finally:
+        exact_ctx.close()
+    assert np.array_equal(hinv_f, hinv_e)
+    assert np.array_equal(out_f, out_e)
+    if np.array_equal(hinv_f, hinv_ref):         # (nearly singular random cells may differ from numpy's inverse by an ulp)
+        assert np.array_equal(out_f, ref)
 
 
 def test_source_with_a_side_of_2_to_the_24_takes_the_flat_order_kernel(native):
