@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("APAP_HIP_LIB") or os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
+ABI_VERSION = 3          # APAP_ABI_VERSION of include/apap_hip.h
 # kernel slots of apap_ctx_profile_read (include/apap_hip.h)
 PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply", "ransac")
 PROF_SLOTS = len(PROF_NAMES)
@@ -27,7 +28,7 @@ VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1,
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 # options of a context (include/apap_hip.h)
 OPT_SOLVER_VARIANT, OPT_EIGEN_SOLVER, OPT_CAREFUL, OPT_PROFILE, OPT_WANT_WAVES, OPT_WARP_ROWS, OPT_WEIGHT_CHUNK_KB, \
-    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST = range(9)
+    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE = range(10)
 
 
 class ApapError(RuntimeError):
@@ -70,6 +71,7 @@ _vp = C.c_void_p
 SIGNATURES = {
     "apap_last_error": (C.c_char_p, []),
     "apap_version": (C.c_char_p, []),
+    "apap_abi_version": (C.c_int, []),
     "apap_device_count": (C.c_int, []),
     "apap_ctx_create": (C.c_void_p, []),
     "apap_ctx_destroy": (None, [_vp]),
@@ -82,6 +84,7 @@ SIGNATURES = {
     "apap_host_build_denorm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f64p]),
     "apap_local_homography": (C.c_int, [_vp, _f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
                                         C.c_double, _f32p, _f64p, C.c_int]),
+    "apap_local_weights": (C.c_int, [_vp, _f32p, C.c_int, _f64p, C.c_int, C.c_double, C.c_double, _f64p, C.c_int]),
     "apap_local_warp": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
     "apap_local_warp_f64": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _f64p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
@@ -144,6 +147,11 @@ def lib():
             except ImportError:
                 pass
         handle = C.CDLL(LIB_PATH)
+        # a build of another ABI generation keeps the symbol names but not the argument lists: refuse it
+        got = handle.apap_abi_version() if hasattr(handle, "apap_abi_version") else 1
+        if got != ABI_VERSION:
+            raise ApapError(ERR_INVALID_ARG, f"{LIB_PATH} is ABI generation {got}, this binding needs {ABI_VERSION}: rebuild "
+                                             "it (make -C cvx_proj_amd/csrc)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res
@@ -172,7 +180,7 @@ class Context:
 
     _NAMES = {"variant": OPT_SOLVER_VARIANT, "eigen": OPT_EIGEN_SOLVER, "careful": OPT_CAREFUL, "profile": OPT_PROFILE,
               "want_waves": OPT_WANT_WAVES, "warp_rows": OPT_WARP_ROWS, "weight_chunk_kb": OPT_WEIGHT_CHUNK_KB,
-              "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST}
+              "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST, "overlap_pcie": OPT_OVERLAP_PCIE}
 
     def set(self, name, value):
         check(lib().apap_ctx_set_option(self._h, self._NAMES[name], int(value)))
@@ -289,6 +297,21 @@ def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device
                                       rows, cols, float(gamma), float(sigma), _ptr(H, C.c_float),
                                       _ptr(W, C.c_double), device))
     return H, W
+
+
+def local_weights(src, points, gamma, sigma, device=-1, ctx=None):
+    """``max(exp(-|p - s| / sigma^2), gamma)`` for every (sample point p, keypoint s): ``points`` (..., 2) float64
+    -> (..., n) float64.  The weights of reference apap.py:150-153 for any subset of the mesh."""
+    src = as_f32(src, (2,))
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    if pts.shape[-1:] != (2,):
+        raise ValueError(f"points must be (..., 2); got {pts.shape}")
+    n, cells = src.shape[0], pts.size // 2
+    W = np.empty(pts.shape[:-1] + (n,), np.float64)
+    if cells:
+        check(lib().apap_local_weights(_h(ctx), _ptr(src, C.c_float), n, _ptr(pts, C.c_double), cells, float(gamma),
+                                       float(sigma), _ptr(W, C.c_double), device))
+    return W
 
 
 def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=True, device=-1, ctx=None):

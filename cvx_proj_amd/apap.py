@@ -24,7 +24,88 @@ import numpy as np
 from . import _native
 from .apap_utils import final_size, get_mesh, get_vertice, uniform_blend  # noqa: F401  (re-exported like the reference)
 
-__all__ = ["APAP", "get_mesh", "get_vertice", "final_size", "uniform_blend", "save2mat", "run_pair", "main"]
+__all__ = ["APAP", "LazyWeights", "get_mesh", "get_vertice", "final_size", "uniform_blend", "save2mat", "run_pair", "main"]
+
+
+class LazyWeights:
+    """The second return value of ``APAP.local_homography`` (reference apap.py:144,153,169: ``local_weight``,
+    float64 ``(rows, cols, n)``), computed on demand.
+
+    The tensor is 8 n bytes per cell - 640 MB for a 200 x 200 mesh and 2000 keypoints, 6.4 GB at 400 x 400 x
+    5000 - and the reference's own caller never looks at it (apap.py:242).  This object has its ``shape``,
+    ``dtype``, ``ndim``, ``size`` and ``nbytes``; indexing the mesh axes (``W[i, j]``, ``W[2:4]``,
+    ``W[:, 7, :50]``) computes exactly the cells asked for on the GPU; ``np.asarray(W)``, any numpy function,
+    arithmetic and every ndarray method materialise the whole tensor once and keep it.  The values are those of
+    an eager call (the same kernel): ``max(exp(-|vertex - keypoint| / sigma^2), gamma)``."""
+
+    dtype = np.dtype(np.float64)
+
+    def __init__(self, src, vertices, gamma, sigma, device=-1, ctx=None):
+        self._src = _native.as_f32(src, (2,)).copy()
+        self._vertices = np.array(vertices, dtype=np.float64)       # a copy: the caller may reuse its buffer
+        self._par = (float(gamma), float(sigma), device, ctx)
+        self._full = None
+        self.shape = tuple(self._vertices.shape[:2]) + (self._src.shape[0],)
+
+    ndim = 3
+    size = property(lambda self: int(np.prod(self.shape)))
+    nbytes = property(lambda self: self.size * 8)
+
+    def _compute(self, points):
+        gamma, sigma, device, ctx = self._par
+        return _native.local_weights(self._src, points, gamma, sigma, device=device, ctx=ctx)
+
+    def materialize(self):
+        """The whole ``(rows, cols, n)`` float64 array (computed once)."""
+        if self._full is None:
+            self._full = self._compute(self._vertices)
+        return self._full
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __getitem__(self, idx):
+        if self._full is not None:
+            return self._full[idx]
+        key = idx if isinstance(idx, tuple) else (idx,)
+        simple = lambda k: isinstance(k, (int, np.integer, slice))      # noqa: E731
+        if len(key) <= 3 and all(simple(k) for k in key):
+            # pick the cells with the first two indices, compute only those, then apply the keypoint index
+            cells = self._vertices[key[:2]]
+            w = self._compute(cells)
+            return w[(Ellipsis,) + key[2:]] if len(key) == 3 else w
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return (self[i] for i in range(self.shape[0]))
+
+    def __repr__(self):
+        state = "materialised" if self._full is not None else "lazy"
+        return f"LazyWeights(shape={self.shape}, dtype=float64, {state})"
+
+    def __getattr__(self, name):        # ndarray methods and attributes: sum, mean, T, reshape, astype, ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+
+def _delegate(op):
+    def method(self, *args):
+        return getattr(self.materialize(), op)(*args)
+    method.__name__ = op
+    return method
+
+
+for _op in ("add", "sub", "mul", "truediv", "floordiv", "pow", "matmul", "mod", "radd", "rsub", "rmul", "rtruediv",
+            "rpow", "rmatmul", "neg", "pos", "abs", "lt", "le", "gt", "ge", "eq", "ne"):
+    setattr(LazyWeights, f"__{_op}__", _delegate(f"__{_op}__"))
+LazyWeights.__hash__ = None
 
 
 class APAP:
@@ -95,11 +176,16 @@ class APAP:
         """Per-cell weighted DLT.  Returns ``(H, W)`` like reference apap.py:121-169:
         ``H`` float32 ``(rows, cols, 3, 3)``, ``W`` float64 ``(rows, cols, n)``.
 
-        ``return_weights=False`` returns ``None`` for ``W``: the tensor costs ``8 n``
-        bytes per cell of HBM and PCIe traffic and the reference's own caller never
-        reads it (apap.py:242)."""
-        return _native.local_homography(src_point, dst_point, vertices, self.gamma, self.sigma,
-                                        want_weights=return_weights, device=self.device, ctx=self.ctx)
+        ``W`` is a :class:`LazyWeights`: it behaves like the reference's array (shape, dtype, indexing,
+        ``np.asarray``, arithmetic) but its ``8 n`` bytes per cell are only computed and copied when looked at -
+        the reference's own caller never does (apap.py:242), and an unmodified caller should not pay 640 MB of
+        HBM and PCIe traffic per pair for it.  ``return_weights="eager"`` computes the ndarray in the same call
+        (what the reference does); ``return_weights=False`` returns ``None``."""
+        H, W = _native.local_homography(src_point, dst_point, vertices, self.gamma, self.sigma,
+                                        want_weights=(return_weights == "eager"), device=self.device, ctx=self.ctx)
+        if return_weights is True:
+            W = LazyWeights(src_point, vertices, self.gamma, self.sigma, device=self.device, ctx=self.ctx)
+        return H, W
 
     # ---- hot loop 2 ------------------------------------------------------------------
     def local_warp(self, ori_img, local_homography, mesh, progress=False):

@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -103,7 +105,8 @@ int fail(int code, const char *fmt, ...) {
 extern "C" {
 
 const char *apap_last_error(void) { return g_err; }
-const char *apap_version(void) { return "cvx_proj_amd apap-hip 0.1 (gfx950)"; }
+const char *apap_version(void) { return "cvx_proj_amd apap-hip " APAP_ABI_VERSION_STRING " (gfx950)"; }
+int apap_abi_version(void) { return APAP_ABI_VERSION; }
 
 int apap_device_count(void) {
     int count = 0;
@@ -112,6 +115,53 @@ int apap_device_count(void) {
         return 0;
     }
     return count;
+}
+
+// The weight tensor of `cells` cells, streamed through a bounded device buffer (it is 8 n bytes per cell):
+// d_table / d_vert are resident, W_out is the host destination.  1 GiB of device staging by default;
+// APAP_OPT_WEIGHT_CHUNK_KB lets tests force several chunks.
+static int stream_weights(apap_ctx *ctx, apap_ctx *pool, int dev, const void *d_table, int n, const void *d_vert, int cells,
+                          double gamma, double sigma, double *W_out) {
+    const size_t max_bytes = (size_t)apap::opt(ctx, APAP_OPT_WEIGHT_CHUNK_KB) << 10;
+    int chunk = (int)(max_bytes / ((size_t)n * sizeof(double)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > cells) chunk = cells;
+    void *d_W;
+    int rc;
+    if ((rc = slot_get(pool, S_W, (size_t)chunk * n * sizeof(double), dev, &d_W))) return rc;
+    for (int c0 = 0; c0 < cells; c0 += chunk) {
+        const int nc = cells - c0 < chunk ? cells - c0 : chunk;
+        rc = apap_weights_device(ctx, (const double *)d_table, n, (const double *)d_vert + (size_t)2 * c0, nc, gamma,
+                                 sigma, (double *)d_W, nullptr);
+        if (rc) return rc;
+        APAP_HIP_TRY(hipMemcpyAsync(W_out + (size_t)c0 * n, d_W, (size_t)nc * n * sizeof(double),
+                                    hipMemcpyDeviceToHost, nullptr));
+        APAP_HIP_TRY(hipStreamSynchronize(nullptr));
+    }
+    return APAP_OK;
+}
+
+int apap_local_weights(apap_ctx *ctx, const float *src, int n, const double *vertices, int cells, double gamma,
+                       double sigma, double *W_out, int device) {
+    if (!src || !vertices || !W_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_weights: null argument");
+    if (n < 1 || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_weights: n=%d cells=%d", n, cells);
+    PoolLock pl(ctx);
+    int dev;
+    int rc = select_device(device, &dev);
+    if (rc) return rc;
+    // the weight kernel reads a keypoint's (x, y) from columns 30, 31 of its table row
+    std::vector<double> table((size_t)n * APAP_TABLE_STRIDE, 0.0);
+    for (int k = 0; k < n; ++k) {
+        table[(size_t)k * APAP_TABLE_STRIDE + 30] = (double)src[2 * k];
+        table[(size_t)k * APAP_TABLE_STRIDE + 31] = (double)src[2 * k + 1];
+    }
+    const SyncOnExit drain;   // the async copy below reads `table`
+    void *d_table, *d_vert;
+    if ((rc = slot_get(pl.pool, S_TABLE, table.size() * sizeof(double), dev, &d_table))) return rc;
+    if ((rc = slot_get(pl.pool, S_VERT, (size_t)cells * 2 * sizeof(double), dev, &d_vert))) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    APAP_HIP_TRY(hipMemcpyAsync(d_vert, vertices, (size_t)cells * 2 * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    return stream_weights(ctx, pl.pool, dev, d_table, n, d_vert, cells, gamma, sigma, W_out);
 }
 
 int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int n, const double *vertices,
@@ -152,28 +202,242 @@ int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int
                            (const double *)d_denorm, (float *)d_H, d_work, work_bytes, nullptr);
     if (rc) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(H_out, d_H, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, nullptr));
-    if (W_out) {
-        // stream the weight tensor through a bounded device buffer (it is 8 n bytes per cell)
-        // 1 GiB of device staging by default; APAP_OPT_WEIGHT_CHUNK_KB lets tests force several chunks
-        const size_t max_bytes = (size_t)apap::opt(ctx, APAP_OPT_WEIGHT_CHUNK_KB) << 10;
-        int chunk = (int)(max_bytes / ((size_t)n * sizeof(double)));
-        if (chunk < 1) chunk = 1;
-        if (chunk > cells) chunk = cells;
-        void *d_W;
-        if ((rc = slot_get(pl.pool, S_W, (size_t)chunk * n * sizeof(double), dev, &d_W))) return rc;
-        for (int c0 = 0; c0 < cells; c0 += chunk) {
-            const int nc = cells - c0 < chunk ? cells - c0 : chunk;
-            rc = apap_weights_device(ctx, (const double *)d_table, n, (const double *)d_vert + (size_t)2 * c0, nc, gamma,
-                                     sigma, (double *)d_W, nullptr);
-            if (rc) return rc;
-            APAP_HIP_TRY(hipMemcpyAsync(W_out + (size_t)c0 * n, d_W, (size_t)nc * n * sizeof(double),
-                                        hipMemcpyDeviceToHost, nullptr));
-            APAP_HIP_TRY(hipStreamSynchronize(nullptr));
-        }
-    }
+    if (W_out && (rc = stream_weights(ctx, pl.pool, dev, d_table, n, d_vert, cells, gamma, sigma, W_out))) return rc;
     APAP_HIP_TRY(hipStreamSynchronize(nullptr));
     return APAP_OK;
 }
+
+// ---- apap_local_warp / apap_local_stitch with PCIe overlapped ---------------------------------------
+// The call moves 25 MB up and 27 MB down around a 20 us kernel (4K pair): one after the other that is
+// ~1.1 ms, almost all of it PCIe one way at a time.  Here the caller's buffers are pinned for the call, the
+// source image goes up in row chunks on one stream, the canvas is warped in row bands on a second - band b
+// as soon as the source rows it can read have landed - and every finished band goes down on a third while
+// later chunks are still going up.  Measured on the MI355X boxes of this pool (APAP_TRACE_PIPE build, 4K pair):
+// 0.93 ms against 1.14 ms - the two directions do NOT add up here: 25 MB up alone and 27 MB down alone each move
+// at ~56 GB/s, both together at ~60 GB/s in all (the same with the canvas written straight into the pinned host
+// buffer by the kernel instead of a DMA copy), so what the overlap hides is the kernels, the set-up and the
+// per-copy latencies, not half of the bytes.
+// WHICH source rows a band can read is not guessed: the set-up kernel reports, per cell row, an interval that
+// contains the source row of every pixel of every cell in it (anchor row -+ the bound of the float32
+// estimate's magnitude, apap_kernels.hip fast_record), and the host takes the union over the band's cell
+// rows.  Meshes the set-up has no such interval for (irregular edges, cells wider than 254 pixels, a
+// perspective denominator that changes sign inside a cell) wait for the whole image: the order of the
+// transfers changes, never the bytes of the canvas.
+namespace {
+
+struct PinGuard {       // hipHostRegister for the duration of a call
+    void *p = nullptr;
+    bool pin(const void *ptr, size_t bytes, unsigned flags = hipHostRegisterDefault) {
+        if (hipHostRegister(const_cast<void *>(ptr), bytes, flags) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        p = const_cast<void *>(ptr);
+        return true;
+    }
+    ~PinGuard() {
+        if (p) (void)hipHostUnregister(p);
+    }
+};
+
+int pipe_prepare(apap_ctx *pool, int dev, size_t n_events, size_t pinned_bytes) {
+    if (pool->pipe_dev != dev) {     // streams and events belong to a device
+        for (void *e : pool->events) (void)hipEventDestroy((hipEvent_t)e);
+        pool->events.clear();
+        for (void *&st : pool->streams) {
+            if (st) (void)hipStreamDestroy((hipStream_t)st);
+            st = nullptr;
+        }
+        pool->pipe_dev = dev;
+    }
+    for (void *&st : pool->streams)
+        if (!st) {
+            hipStream_t h;
+            APAP_HIP_TRY(hipStreamCreateWithFlags(&h, hipStreamNonBlocking));
+            st = h;
+        }
+    while (pool->events.size() < n_events) {
+        hipEvent_t e;
+        APAP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pool->events.push_back(e);
+    }
+    if (pool->pinned_cap < pinned_bytes) {
+        if (pool->pinned) (void)hipHostFree(pool->pinned);
+        pool->pinned = nullptr;
+        pool->pinned_cap = 0;
+        APAP_HIP_TRY(hipHostMalloc(&pool->pinned, pinned_bytes, hipHostMallocDefault));
+        pool->pinned_cap = pinned_bytes;
+    }
+    return APAP_OK;
+}
+
+struct DrainStreams {    // whatever way the function is left, nothing of it is still running
+    apap_ctx *pool;
+    ~DrainStreams() {
+        for (void *st : pool->streams)
+            if (st) (void)hipStreamSynchronize((hipStream_t)st);
+    }
+};
+
+// rows of `total` in `parts` near-equal pieces: piece i = [cut(i), cut(i + 1))
+inline int cut(int total, int parts, int i) { return (int)((long long)total * i / parts); }
+
+// Returns APAP_OK and sets *done = true when the call was served here; *done = false (and APAP_OK) when the
+// caller should take the plain sequential path (pinning refused, a mesh without the fast tables).
+int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, int img_h, int img_w, const uint8_t *center,
+                    int center_h, int center_w, const float *Hfwd, int mesh_rows, int mesh_cols, const double *mesh_w,
+                    int n_w, const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *out,
+                    float *Hinv_out, const char *who, bool *done) {
+    *done = false;
+#ifdef APAP_TRACE_PIPE      // diagnostic build: host-side timeline of the call on stderr
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        fprintf(stderr, "[pipe] %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+#else
+    auto stamp = [](const char *) {};
+#endif
+    const size_t img_bytes = (size_t)img_h * img_w * 3, out_bytes = (size_t)final_w * final_h * 3;
+    const size_t cbytes = center ? (size_t)center_h * center_w * 3 : 0;
+    if (img_bytes + out_bytes < (8u << 20)) return APAP_OK;      // small pairs: one copy each way is as good
+    const int cells = mesh_rows * mesh_cols;
+    const int chunks = (int)std::min<size_t>(16, std::max<size_t>(2, img_bytes / (3u << 20)));
+    const int bands = (int)std::min<size_t>(16, std::max<size_t>(2, out_bytes / (3u << 20)));
+    const size_t range_ints = (size_t)mesh_rows * 2 + 2;
+    int rc = pipe_prepare(pool, dev, (size_t)2 * chunks + bands + 2, range_ints * sizeof(int) + 64);
+    if (rc) return rc;
+    PinGuard pin_img, pin_out, pin_center, pin_H, pin_Hinv;
+    if (!pin_img.pin(img, img_bytes) || !pin_out.pin(out, out_bytes) ||
+        (center && !pin_center.pin(center, cbytes)) || !pin_H.pin(Hfwd, (size_t)cells * 9 * sizeof(float)) ||
+        (Hinv_out && !pin_Hinv.pin(Hinv_out, (size_t)cells * 9 * sizeof(float))))
+        return APAP_OK;
+
+    stamp("pinned");
+    const size_t work_bytes = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
+    void *d_H, *d_mw, *d_mh, *d_work, *d_status, *d_hinv = nullptr, *d_img, *d_out, *d_center = nullptr;
+    if ((rc = slot_get(pool, S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
+    if ((rc = slot_get(pool, S_MESHW, (size_t)n_w * sizeof(double), dev, &d_mw))) return rc;
+    if ((rc = slot_get(pool, S_MESHH, (size_t)n_h * sizeof(double), dev, &d_mh))) return rc;
+    if ((rc = slot_get(pool, S_WORK, work_bytes, dev, &d_work))) return rc;
+    if ((rc = slot_get(pool, S_STATUS, sizeof(int), dev, &d_status))) return rc;
+    if (Hinv_out && (rc = slot_get(pool, S_HINV, (size_t)cells * 9 * sizeof(float), dev, &d_hinv))) return rc;
+    if ((rc = slot_get(pool, S_IMG, img_bytes, dev, &d_img))) return rc;
+    if ((rc = slot_get(pool, S_OUT, out_bytes, dev, &d_out))) return rc;
+    if (center && (rc = slot_get(pool, S_AUX, cbytes, dev, &d_center))) return rc;
+
+    hipStream_t s_up = (hipStream_t)pool->streams[0], s_k = (hipStream_t)pool->streams[1], s_dn = (hipStream_t)pool->streams[2];
+    hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(pool->events.data());
+    hipEvent_t *e_img = ev, *e_cen = ev + chunks, *e_band = ev + 2 * chunks, e_setup = ev[2 * chunks + bands];
+    int *h_rng = (int *)pool->pinned;
+    int status = 0;
+    const DrainStreams drain{pool};     // declared after everything the streams read or write
+
+    // upload stream: source rows (and the centre image's) in chunks, an event after each
+    for (int c = 0; c < chunks; ++c) {
+        const size_t a = (size_t)cut(img_h, chunks, c) * img_w * 3, b = (size_t)cut(img_h, chunks, c + 1) * img_w * 3;
+        if (b > a) APAP_HIP_TRY(hipMemcpyAsync((char *)d_img + a, img + a, b - a, hipMemcpyHostToDevice, s_up));
+        APAP_HIP_TRY(hipEventRecord(e_img[c], s_up));
+        if (center) {
+            const size_t ca = (size_t)cut(center_h, chunks, c) * center_w * 3, cb = (size_t)cut(center_h, chunks, c + 1) * center_w * 3;
+            if (cb > ca) APAP_HIP_TRY(hipMemcpyAsync((char *)d_center + ca, center + ca, cb - ca, hipMemcpyHostToDevice, s_up));
+            APAP_HIP_TRY(hipEventRecord(e_cen[c], s_up));
+        }
+    }
+
+    stamp("uploads enqueued");
+    // kernels stream: grid and edges up, set-up kernel, its source-row intervals back
+    int *d_src_rows = nullptr;
+    APAP_HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s_k));
+    APAP_HIP_TRY(hipMemcpyAsync(d_H, Hfwd, (size_t)cells * 9 * sizeof(float), hipMemcpyHostToDevice, s_k));
+    APAP_HIP_TRY(hipMemcpyAsync(d_mw, mesh_w, (size_t)n_w * sizeof(double), hipMemcpyHostToDevice, s_k));
+    APAP_HIP_TRY(hipMemcpyAsync(d_mh, mesh_h, (size_t)n_h * sizeof(double), hipMemcpyHostToDevice, s_k));
+    {
+        // where the intervals will live (the same layout the set-up uses); lower bounds start high, upper bounds low
+        int *probe = nullptr;
+        rc = apap::warp_phase(ctx, (const uint8_t *)d_img, img_h, img_w, (const uint8_t *)d_center, center_h, center_w,
+                              (const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w, (const double *)d_mh, n_h,
+                              final_w, final_h, off_x, off_y, (uint8_t *)d_out, (float *)d_hinv, d_work, work_bytes,
+                              (int *)d_status, s_k, 0, 0, 0, &probe);
+        if (rc) return rc;
+        if (!probe) return APAP_OK;     // a mesh the fast tables do not cover: sequential path
+        // one interleaved fill: even words (lower bounds) 0x7f7f7f7f, odd words (upper bounds) 0x80808080
+        std::vector<int> init(range_ints);
+        for (int r = 0; r < mesh_rows; ++r) {
+            init[2 * r] = 0x7f7f7f7f;
+            init[2 * r + 1] = (int)0x80808080u;
+        }
+        init[2 * mesh_rows] = init[2 * mesh_rows + 1] = 0;
+        memcpy(h_rng, init.data(), range_ints * sizeof(int));
+        // (h_rng is reused for the read-back below: the same stream, so the device has read it by then)
+        APAP_HIP_TRY(hipMemcpyAsync(probe, h_rng, range_ints * sizeof(int), hipMemcpyHostToDevice, s_k));
+    }
+    rc = apap::warp_phase(ctx, (const uint8_t *)d_img, img_h, img_w, (const uint8_t *)d_center, center_h, center_w,
+                          (const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w, (const double *)d_mh, n_h, final_w,
+                          final_h, off_x, off_y, (uint8_t *)d_out, (float *)d_hinv, d_work, work_bytes, (int *)d_status, s_k, 0, 0,
+                          apap::kWarpSetup, &d_src_rows);
+    if (rc) return rc;
+    APAP_HIP_TRY(hipMemcpyAsync(h_rng, d_src_rows, range_ints * sizeof(int), hipMemcpyDeviceToHost, s_k));
+    APAP_HIP_TRY(hipEventRecord(e_setup, s_k));
+    if (Hinv_out)
+        APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, s_k));
+
+    // the intervals: which chunk must have landed before band b may run
+    stamp("set-up enqueued");
+    APAP_HIP_TRY(hipEventSynchronize(e_setup));
+    stamp("set-up done");
+    const bool irregular = (h_rng[2 * mesh_rows] & 1) != 0;
+    auto cell_row_of = [&](int y) {     // "first k with y < mesh_h[k]" - 1 on increasing edges
+        const int k = (int)(std::upper_bound(mesh_h, mesh_h + n_h, (double)y) - mesh_h) - 1;
+        return std::min(std::max(k, 0), mesh_rows - 1);
+    };
+    auto chunk_of_row = [&](int total, int row) {      // the chunk that holds `row`
+        int c = (int)(((long long)row + 1) * chunks / std::max(total, 1));
+        c = std::min(std::max(c, 0), chunks - 1);
+        while (c > 0 && cut(total, chunks, c) > row) --c;
+        while (c + 1 < chunks && cut(total, chunks, c + 1) <= row) ++c;
+        return c;
+    };
+    for (int b = 0; b < bands; ++b) {
+        const int y0 = cut(final_h, bands, b), y1 = cut(final_h, bands, b + 1);
+        if (y1 <= y0) {
+            APAP_HIP_TRY(hipEventRecord(e_band[b], s_k));
+            continue;
+        }
+        int need = chunks - 1;      // without intervals: the whole image
+        if (!irregular) {
+            long long hi = -1;
+            for (int r = cell_row_of(y0); r <= cell_row_of(y1 - 1); ++r) hi = std::max<long long>(hi, h_rng[2 * r + 1]);
+            hi = std::min<long long>(hi + 1, img_h - 1);      // + 1: the gather's dword may reach into the next row
+            need = hi < 0 ? 0 : chunk_of_row(img_h, (int)hi);
+        }
+        APAP_HIP_TRY(hipStreamWaitEvent(s_k, e_img[need], 0));
+        if (center) {
+            const int c_hi = std::min(std::max(y1 - 1 - off_y, 0), center_h - 1);
+            APAP_HIP_TRY(hipStreamWaitEvent(s_k, e_cen[chunk_of_row(center_h, c_hi)], 0));
+        }
+        uint8_t *d_band = (uint8_t *)d_out + (size_t)y0 * final_w * 3;
+        rc = apap::warp_phase(ctx, (const uint8_t *)d_img, img_h, img_w, (const uint8_t *)d_center, center_h, center_w,
+                              (const float *)d_H, mesh_rows, mesh_cols, (const double *)d_mw, n_w, (const double *)d_mh, n_h,
+                              final_w, final_h, off_x, off_y, d_band, nullptr, d_work, work_bytes, (int *)d_status, s_k, y0,
+                              y1 - y0, apap::kWarpRows, nullptr);
+        if (rc) return rc;
+        APAP_HIP_TRY(hipEventRecord(e_band[b], s_k));
+        APAP_HIP_TRY(hipStreamWaitEvent(s_dn, e_band[b], 0));
+        APAP_HIP_TRY(hipMemcpyAsync(out + (size_t)y0 * final_w * 3, d_band, (size_t)(y1 - y0) * final_w * 3, hipMemcpyDeviceToHost, s_dn));
+    }
+    stamp("bands enqueued");
+    APAP_HIP_TRY(hipMemcpyAsync(h_rng, d_status, sizeof(int), hipMemcpyDeviceToHost, s_k));
+    APAP_HIP_TRY(hipStreamSynchronize(s_k));
+    stamp("kernels done");
+    status = h_rng[0];
+    APAP_HIP_TRY(hipStreamSynchronize(s_dn));
+    stamp("downloads done");
+    APAP_HIP_TRY(hipStreamSynchronize(s_up));
+    *done = true;
+    return status_to_code(status, who);
+}
+
+}  // namespace
 
 // `h_bytes` = 4: the grid (and Hinv_out) is float32; 8: float64 (apap_local_warp_f64 only).
 static int warp_common(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, const uint8_t *center, int center_h,
@@ -188,6 +452,12 @@ static int warp_common(apap_ctx *ctx, const uint8_t *img, int img_h, int img_w, 
     int dev;
     int rc = select_device(device, &dev);
     if (rc) return rc;
+    if (!coords && h_bytes == sizeof(float) && apap::opt(ctx, APAP_OPT_OVERLAP_PCIE)) {
+        bool done = false;
+        rc = warp_overlapped(ctx, pl.pool, dev, img, img_h, img_w, center, center_h, center_w, (const float *)Hfwd, mesh_rows,
+                             mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h, off_x, off_y, out, (float *)Hinv_out, who, &done);
+        if (rc || done) return rc;
+    }
     const int cells = mesh_rows * mesh_cols;
     const size_t work_bytes = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
     const size_t pixels = (size_t)final_w * final_h;

@@ -27,10 +27,17 @@ enum { S_TABLE, S_VERT, S_DENORM, S_H, S_WORK, S_W, S_IMG, S_OUT, S_MESHW, S_MES
 // The context of include/apap_hip.h: options, profiling events, device-buffer pool.  Nothing else
 // in the library is mutable after load.
 struct apap_ctx {
-    int opt[APAP_OPT_COUNT] = {APAP_VARIANT_AUTO, APAP_EIGEN_AUTO, 1, 0, 4096, 4, 1 << 20, 4096, 1};
+    int opt[APAP_OPT_COUNT] = {APAP_VARIANT_AUTO, APAP_EIGEN_AUTO, 1, 0, 4096, 4, 1 << 20, 4096, 1, 1};
     std::vector<apap::ProfSpan> spans;
     apap::DevSlot slots[apap::S_COUNT];
     std::mutex mu;   // serialises the host-buffer entry points that share this context's pool
+    // overlap of PCIe and kernels in apap_local_warp / apap_local_stitch: three streams (upload, kernels,
+    // download), their events, a small pinned buffer for what the host reads back mid-call; made on first use
+    void *streams[3] = {nullptr, nullptr, nullptr};
+    std::vector<void *> events;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+    int pipe_dev = -1;
 };
 
 namespace apap {
@@ -72,6 +79,18 @@ struct SolvePlan {
     size_t moment_bytes;
 };
 SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves);
+
+// ---- the warp in two phases on one workspace (the host-buffer entry points overlap PCIe with it) ----
+constexpr int kWarpSetup = 1;      // cell inverses, fast records, lookup tables (and, if asked, source-row intervals)
+constexpr int kWarpRows = 2;       // the gather kernel over canvas rows [row_begin, row_begin + row_count)
+// apap_warp_rows_device / apap_stitch_device with a choice of phases.  With `d_src_rows` non-null the set-up also
+// fills, per cell row, the interval of source rows its pixels can read (device ints [rows][2], then one flag word:
+// bit 0 = irregular mesh, intervals void); the caller pre-sets the lower bounds to a large and the upper bounds to a
+// small value.  *d_src_rows is set to the device address, or to NULL when this mesh has no such table.
+int warp_phase(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h, int center_w,
+               const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
+               int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out_band, float *d_Hinv_out, void *d_work,
+               size_t work_bytes, int *d_status, void *stream, int row_begin, int row_count, int phase, int **d_src_rows);
 
 constexpr int kMoments = 30;       // distinct sums of A^T W^2 A
 constexpr int kStatusSingular = 1; // bit 0 of the device status word

@@ -1580,8 +1580,10 @@ __device__ __forceinline__ bool fast_origin(const double *__restrict__ edges, in
 }
 
 // the 12-dword record k_warp_fast reads per cell: {a'x, b'x, c'x, a'y | b'y, c'y, t2b, h6 | h7, n0x, n0y, thr}
+// `src_rows` (optional): lower / upper bound of the SOURCE rows the cell's pixels can read - n0y -+ a bound of
+// |estimate| - merged into two ints with atomicMin / atomicMax; a cell without a bound claims every row.
 __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok, double xb, double yb, double DX,
-                                            double DY, float4 *__restrict__ out) {
+                                            double DY, float4 *__restrict__ out, int *src_rows = nullptr) {
     const double eps64 = 1.1102230246251565e-16, eps32 = 5.9604644775390625e-08, unit = 4194304.0;   // 2^22
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
     pc.w = __uint_as_float(0xffffffffu);   // window = everything: den = 0 -> s = NaN -> int(s) = 0 < thr
@@ -1632,11 +1634,16 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
     out[0] = pa;
     out[1] = pb;
     out[2] = pc;
+    if (src_rows) {
+        const int m = ok ? (int)ceil(Smax) + 2 : 0;
+        atomicMin(src_rows, ok ? (int)n0y - m : -2147483647 - 1);
+        atomicMax(src_rows + 1, ok ? (int)n0y + m : 2147483647);
+    }
 }
 
 // Workspace of the warp, in this order (every part rounded up to 256 bytes):
 //   hinv_pad [cells][10] f64 | lut [final_h + final_w] i32 | frec [(rows + 1)(cols + 1)][3] float4 |
-//   fcol [final_w rounded up to 4] u32 | frow [final_h] uint2
+//   fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
 // frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
 // `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row,
 // float bits of dy}, dx / dy = signed distance from the cell's anchor (its middle pixel); pixels that are not
@@ -1647,6 +1654,7 @@ struct WarpWork {
     float4 *frec;
     unsigned *fcol;
     uint2 *frow;
+    int *src_rows;      // [rows][2] source-row interval per cell row, then 1 flag word (bit 0: irregular mesh)
     size_t bytes;
 };
 
@@ -1666,6 +1674,8 @@ inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int f
     p += round256((((size_t)final_w + 3) / 4 * 4) * sizeof(unsigned));
     w.frow = (uint2 *)p;
     p += round256((size_t)final_h * sizeof(uint2));
+    w.src_rows = (int *)p;
+    p += round256(((size_t)mesh_rows * 2 + 2) * sizeof(int));
     w.bytes = (size_t)(p - (char *)base);
     return w;
 }
@@ -1679,7 +1689,11 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
                                                     int mesh_rows, int mesh_cols, int final_w, int final_h,
                                                     int *__restrict__ lut, int *status, int off_x, int off_y,
                                                     float4 *__restrict__ frec, unsigned *__restrict__ fcol,
-                                                    uint2 *__restrict__ frow) {
+                                                    uint2 *__restrict__ frow, int *__restrict__ src_rows) {
+    // src_rows (optional; the host-buffer warp schedules its upload / warp / download bands with it): per
+    // cell row the interval of source rows its pixels can read, [2 r] pre-set to INT_MAX-like, [2 r + 1] to
+    // INT_MIN-like by the caller; word [2 rows]: bit 0 set when some canvas pixel is not inside an ordinary cell
+    // (then the intervals say nothing).
     __shared__ double pm[2][kMaxEdges];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < inv_blocks) {
@@ -1719,7 +1733,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         }
         // anchor in the middle of the cell: the estimate's error grows with the distance from it
         fast_record(hd, okx && oky, (double)(x0 + sx / 2 - off_x), (double)(y0 + sy / 2 - off_y), (double)(sx - sx / 2),
-                    (double)(sy - sy / 2), frec + (size_t)e * 3);
+                    (double)(sy - sy / 2), frec + (size_t)e * 3, src_rows ? src_rows + 2 * er : nullptr);
         return;
     }
     const int row_blocks = (final_h + 1023) / 1024;
@@ -1764,6 +1778,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         const int d = idx - x0;
         const bool in = ok && d >= 0 && d < span;
         const unsigned fc = in ? (unsigned)c : (unsigned)ncell;
+        if (!in && src_rows) atomicOr(src_rows + 2 * mesh_rows, 1);
         const int rel = in ? d - span / 2 : 0;       // distance from the cell's anchor (its middle pixel), -127 ... 127
         const unsigned fd = (unsigned)(rel + 128);
         if (is_row) {
@@ -2442,6 +2457,10 @@ void apap_ctx_destroy(apap_ctx *ctx) {
     }
     for (apap::DevSlot &sl : ctx->slots)
         if (sl.ptr) (void)hipFree(sl.ptr);
+    for (void *e : ctx->events) (void)hipEventDestroy((hipEvent_t)e);
+    for (void *st : ctx->streams)
+        if (st) (void)hipStreamDestroy((hipStream_t)st);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     delete ctx;
 }
 
@@ -2457,7 +2476,8 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 2 || value == 4 || value == 8; break;
         case APAP_OPT_WEIGHT_CHUNK_KB: ok = value >= 1; break;
         case APAP_OPT_FUSED_MAX_CELLS: ok = value >= 0; break;
-        case APAP_OPT_WARP_FAST: ok = value == 0 || value == 1; break;
+        case APAP_OPT_WARP_FAST:
+        case APAP_OPT_OVERLAP_PCIE: ok = value == 0 || value == 1; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
     }
     if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
@@ -2601,7 +2621,8 @@ template <typename T>
 static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
                          int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
                          T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                         hipStream_t s, int off_x, int off_y, WarpWork *ww, bool *fast_tables) {
+                         hipStream_t s, int off_x, int off_y, WarpWork *ww, bool *fast_tables, int phase = apap::kWarpSetup,
+                         bool want_src_rows = false) {
     if (!d_Hfwd || !d_mesh_w || !d_mesh_h || !d_work || !d_status)
         return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
     if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
@@ -2610,16 +2631,17 @@ static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh
     if (work_bytes < need) return apap::fail(APAP_ERR_WORKSPACE, "warp: workspace %zu < %zu bytes", work_bytes, need);
     const int cells = mesh_rows * mesh_cols;
     *ww = warp_work_layout(d_work, mesh_rows, mesh_cols, final_w, final_h);
-    *fast_tables = false;
-    if (n_w <= kMaxEdges && n_h <= kMaxEdges && mesh_rows < 65535 && mesh_cols < 65535) {
+    *fast_tables = n_w <= kMaxEdges && n_h <= kMaxEdges && mesh_rows < 65535 && mesh_cols < 65535;
+    if (!(phase & apap::kWarpSetup)) return APAP_OK;     // the tables of an earlier call on this workspace are used
+    if (*fast_tables) {
         // one launch: cell inverses + fast records + lookup tables (reported under the INVERT slot)
         ProfScope prof(ctx, APAP_PROF_INVERT, s);
         const int inv_blocks = (int)(((size_t)(mesh_rows + 1) * (mesh_cols + 1) + 255) / 256);
         const int lut_blocks = (final_h + 1023) / 1024 + (final_w + 1023) / 1024;
         hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, ww->hinv_pad,
                            d_Hinv_out, inv_blocks, d_mesh_w, n_w, d_mesh_h, n_h, mesh_rows, mesh_cols, final_w,
-                           final_h, ww->lut, d_status, off_x, off_y, ww->frec, ww->fcol, ww->frow);
-        *fast_tables = true;
+                           final_h, ww->lut, d_status, off_x, off_y, ww->frec, ww->fcol, ww->frow,
+                           want_src_rows ? ww->src_rows : (int *)nullptr);
     } else {
         {
             ProfScope prof(ctx, APAP_PROF_INVERT, s);
@@ -2641,7 +2663,8 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
                      int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                     void *stream, int row_begin, int row_count) {
+                     void *stream, int row_begin, int row_count, int phase = apap::kWarpSetup | apap::kWarpRows,
+                     int **d_src_rows = nullptr) {
     if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
     if (row_begin < 0 || row_count < 0 || (long long)row_begin + row_count > final_h)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_rows_device: rows [%d, %d) outside the canvas of %d rows",
@@ -2668,11 +2691,13 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
     WarpWork ww;
     bool fast_tables;
     const int rc = warp_prologue<T>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                    d_Hinv_out, d_work, work_bytes, d_status, s, off_x, off_y, &ww, &fast_tables);
+                                    d_Hinv_out, d_work, work_bytes, d_status, s, off_x, off_y, &ww, &fast_tables, phase,
+                                    d_src_rows != nullptr);
     if (rc != APAP_OK) return rc;
+    if (d_src_rows) *d_src_rows = fast_tables ? ww.src_rows : nullptr;
     double *hinv_pad = ww.hinv_pad;
     int *lut = ww.lut;
-    if (row_count == 0) return APAP_OK;  // an empty band: only the set-up kernel ran
+    if (row_count == 0 || !(phase & apap::kWarpRows)) return APAP_OK;  // an empty band: only the set-up kernel ran
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
     // APAP_OPT_WARP_ROWS (experiments): 0 = flat-order kernel, 2 / 4 / 8 = row strips of that many
@@ -2734,6 +2759,17 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
     return APAP_OK;
 }
+
+namespace apap {
+int warp_phase(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h, int center_w,
+               const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
+               int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out_band, float *d_Hinv_out, void *d_work,
+               size_t work_bytes, int *d_status, void *stream, int row_begin, int row_count, int phase, int **d_src_rows) {
+    return warp_impl<float>(ctx, d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
+                            d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out_band, d_Hinv_out, d_work, work_bytes, d_status,
+                            stream, row_begin, row_count, phase, d_src_rows);
+}
+}  // namespace apap
 
 extern "C" {
 

@@ -77,9 +77,18 @@ extern "C" {
 #define APAP_PROF_RANSAC 7   /* R1-R3: hypotheses, scoring, selection   */
 #define APAP_PROF_SLOTS 8
 
+/* ABI generation.  Generation 2 put `apap_ctx *` first in every compute entry point while keeping the
+ * symbol names of generation 1: a caller built against the old header would still link and then pass a
+ * float* where the context goes.  Such a caller must refuse to run: check apap_abi_version() ==
+ * APAP_ABI_VERSION once after loading (cvx_proj_amd/_native.py does); a generation-1 library does not
+ * export the symbol at all.  Bump on any change of an existing signature. */
+#define APAP_ABI_VERSION 3
+#define APAP_ABI_VERSION_STRING "0.3"
+
 /* ---------------------------------------------------------------- diagnostics --- */
 const char *apap_last_error(void);
 const char *apap_version(void);
+int apap_abi_version(void);
 /* Number of visible HIP devices; 0 when there is none (never an error). */
 int apap_device_count(void);
 
@@ -106,7 +115,10 @@ typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_WARP_FAST 8       /* 1 (default): K3 decides a pixel from a float32 estimate of its source coordinate
                                       and takes the exact float64 sequence only where the estimate is within its error
                                       bound of an integer (same canvas, byte for byte); 0: float64 for every pixel    */
-#define APAP_OPT_COUNT 9
+#define APAP_OPT_OVERLAP_PCIE 9    /* 1 (default): apap_local_warp / apap_local_stitch pin the caller's buffers for the call
+                                      and overlap the image upload, the warp (in row bands) and the canvas download on
+                                      three streams; 0: one copy up, one kernel, one copy down                         */
+#define APAP_OPT_COUNT 10
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);
@@ -154,6 +166,13 @@ int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, 
 int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int n, const double *vertices,
                           int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
                           double *W_out, int device);
+
+/* The second return value of APAP.local_homography alone (apap.py:144,150-153,169): W_out[c][k] =
+ * max(exp(-|vertices[c] - src[k]| / sigma^2), gamma), cells x n float64, for ANY list of `cells` sample points
+ * (the whole mesh, or the cells a caller indexes: cvx_proj_amd.apap.LazyWeights).  The reference's own caller
+ * never reads this tensor (apap.py:242); computing it on demand keeps its 8 n bytes per cell off the default path. */
+int apap_local_weights(apap_ctx *ctx, const float *src, int n, const double *vertices, int cells, double gamma,
+                       double sigma, double *W_out, int device);
 
 /* APAP.local_warp (apap.py:186-217).
  *   img        img_h x img_w x 3 uint8

@@ -1,0 +1,106 @@
+"""``APAP.local_homography``'s second return value is a LazyWeights (cvx_proj_amd/apap.py): the reference's
+``local_weight`` array (apap.py:144,153,169), computed when looked at.  Host logic on the CPU (the compute
+injected from the oracle's formula); values against the reference's tensors on the GPU."""
+import numpy as np
+import pytest
+
+from cvx_proj_amd import _native
+from cvx_proj_amd.apap import APAP, LazyWeights
+
+
+def oracle_weights(src, points, gamma, sigma, device=-1, ctx=None):
+    """apap.py:150-153 for arbitrary sample points."""
+    pts = np.asarray(points, np.float64)
+    d = np.sqrt(((pts[..., None, :] - np.asarray(src, np.float32).astype(np.float64)) ** 2).sum(-1))
+    return np.maximum(np.exp(-d / (sigma * sigma)), gamma)
+
+
+@pytest.fixture
+def lazy(monkeypatch):
+    calls = []
+
+    def fake(src, points, gamma, sigma, device=-1, ctx=None):
+        calls.append(np.asarray(points).shape)
+        return oracle_weights(src, points, gamma, sigma)
+    monkeypatch.setattr(_native, "local_weights", fake)
+    rng = np.random.default_rng(3)
+    src = (rng.random((37, 2)) * 300).astype(np.float32)
+    vertices = rng.random((6, 9, 2)) * 300
+    W = LazyWeights(src, vertices, 0.5, 12.0)
+    return W, oracle_weights(src, vertices, 0.5, 12.0), calls
+
+
+def test_looks_like_the_reference_array(lazy):
+    W, full, calls = lazy
+    assert W.shape == (6, 9, 37) and W.dtype == np.float64 and W.ndim == 3 and W.size == 6 * 9 * 37 and len(W) == 6
+    assert W.nbytes == full.nbytes and calls == []          # nothing computed yet
+    assert "lazy" in repr(W)
+
+
+@pytest.mark.parametrize("idx", [(2, 3), 4, (slice(1, 3),), (slice(None), 7), (5, slice(2, 8, 3)), (1, 2, 5),
+                                 (slice(None), slice(None), slice(0, 10)), (-1, -1), (0, 0, slice(None, None, -1))])
+def test_mesh_indexing_computes_only_the_cells_asked_for(lazy, idx):
+    W, full, calls = lazy
+    got = W[idx]
+    assert np.array_equal(got, full[idx])
+    whole = idx == (slice(None), slice(None), slice(0, 10))
+    assert len(calls) == 1 and (whole or np.prod(calls[0][:-1]) < 6 * 9)      # only the cells asked for went to the device
+    assert W._full is None
+
+
+def test_everything_else_materialises_once(lazy):
+    W, full, calls = lazy
+    assert np.array_equal(np.asarray(W), full) and calls == [(6, 9, 2)]
+    assert np.array_equal(W[W > 0.9], full[full > 0.9])            # boolean mask: the full tensor
+    assert np.array_equal(W * 2 + 1, full * 2 + 1) and np.array_equal(1 - W, 1 - full)
+    assert W.sum() == full.sum() and np.array_equal(W.T, full.T) and np.array_equal(np.exp(W), np.exp(full))
+    assert np.array_equal(W.reshape(-1, 37)[5], full.reshape(-1, 37)[5])
+    assert np.array_equal([row for row in W][3], full[3])
+    assert np.array_equal(np.asarray(W, dtype=np.float32), full.astype(np.float32))
+    assert calls == [(6, 9, 2)] and "materialised" in repr(W)      # one device call in all
+    assert np.array_equal(W[2, 3], full[2, 3])                      # indexing now reads the kept tensor
+    with pytest.raises(TypeError):
+        hash(W)
+
+
+def test_copies_its_inputs(lazy, monkeypatch):
+    monkeypatch.setattr(_native, "local_weights", oracle_weights)
+    src = np.ones((4, 2), np.float32)
+    vert = np.zeros((2, 2, 2))
+    W = LazyWeights(src, vert, 0.1, 3.0)
+    expect = oracle_weights(src, vert, 0.1, 3.0)
+    src += 5
+    vert += 7
+    assert np.array_equal(np.asarray(W), expect)
+
+
+# ------------------------------------------------------------------------------------ on the GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny_sigma100", "tiny_sigma6"])
+def test_values_equal_the_reference_tensor(native, golden, name):
+    g = golden(name)
+    fw, fh, ox, oy = (int(v) for v in g["final"])
+    eng = APAP(float(g["gamma"]), float(g["sigma"]), [fw, fh], [ox, oy])
+    H, W = eng.local_homography(g["src"], g["dst"], g["vertices"])          # the reference's signature
+    assert isinstance(W, LazyWeights) and W.shape == g["W_ref"].shape
+    assert np.allclose(W[1, 2], g["W_ref"][1, 2], rtol=8e-15, atol=0)
+    assert np.allclose(W[3], g["W_ref"][3], rtol=8e-15, atol=0)
+    assert np.allclose(W[:, 4, 10:20], g["W_ref"][:, 4, 10:20], rtol=8e-15, atol=0)
+    full = np.asarray(W)
+    assert np.allclose(full, g["W_ref"], rtol=8e-15, atol=0)
+    # the same bits as the eager tensor of the same call site
+    _, W_eager = eng.local_homography(g["src"], g["dst"], g["vertices"], return_weights="eager")
+    assert isinstance(W_eager, np.ndarray) and np.array_equal(full, W_eager)
+    assert eng.local_homography(g["src"], g["dst"], g["vertices"], return_weights=False)[1] is None
+
+
+@pytest.mark.gpu
+def test_checksum_of_c2_through_the_lazy_object(native, golden):
+    from cvx_proj_amd.synth import config_pair
+    g = golden("c2_ref")
+    p = config_pair("C2", with_image=False)
+    eng = APAP(p.gamma, p.sigma, [p.final_w, p.final_h], [p.off_x, p.off_y])
+    _, W = eng.local_homography(p.src, p.dst, p.vertices)
+    assert np.allclose(W[0, 0], g["W_row0"], rtol=1e-14) and np.allclose(W[-1, -1], g["W_last"], rtol=1e-14)
+    assert W._full is None
+    assert np.allclose([W.sum(), (W * W).sum()], g["W_checksum"], rtol=1e-13)
