@@ -317,6 +317,44 @@ def call_level(cfg, reps=7):
                     "with_weights = the eager 640 MB tensor"}
 
 
+def pipeline_level(cfg, reps=5):
+    """apap.py __main__ between loading and saving (apap.py:238-264), numpy in -> the `.mat` array (and the canvas)
+    out: the resident pass of cvx_proj_amd.pipeline against the chain of calls of the mirror class."""
+    from cvx_proj_amd import apap as A
+    from cvx_proj_amd.pipeline import Pipeline
+    p = config_pair(cfg)
+    m = p.vertices.shape[0]
+    pipe = Pipeline()
+
+    def med(f, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            f()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2]
+
+    args = (p.src, p.dst, p.Hg, p.shape, p.shape, m, p.gamma, p.sigma)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):          # the mirror class prints the reference's progress lines
+        pipe.run_pair(*args, other_img=p.img)                # warm-up: buffers
+        A.run_pair_by_calls(*args, other_img=p.img)
+        t_solve = med(lambda: pipe.run_pair(*args), reps)
+        tl_solve = dict(pipe.timeline)
+        t_warp = med(lambda: pipe.run_pair(*args, other_img=p.img), reps)
+        tl_warp = dict(pipe.timeline)
+        c_solve = med(lambda: A.run_pair_by_calls(*args), reps)
+        c_warp = med(lambda: A.run_pair_by_calls(*args, other_img=p.img), max(reps - 2, 3))
+    return {"workload": cfg, "solve_to_mat_array_ms": t_solve * 1e3, "solve_warp_to_mat_array_and_canvas_ms": t_warp * 1e3,
+            "chain_of_calls_solve_ms": c_solve * 1e3, "chain_of_calls_solve_warp_ms": c_warp * 1e3,
+            "timeline_solve": tl_solve, "timeline_solve_warp": tl_warp,
+            "note": "numpy in -> numpy out, everything between resident in HBM on one stream, one trip back "
+                    "(cvx_proj_amd/pipeline.py); chain_of_calls = the mirror class call by call as apap.py:238-264 is written "
+                    "(local_homography, local_warp with its own copy of the grid, invert_normalize_flatten); with the warp both "
+                    "are bound by 25 MB up + 27 MB down over PCIe; never `value`"}
+
+
 # ------------------------------------------------------------------------------------ self-launch
 def free_port():
     with socket.socket() as s:
@@ -694,6 +732,7 @@ def main():
                         f"warped in rotation: every launch reads its source from HBM and writes a canvas that is not cached"}
         if world == 1 and not a.no_call_level:
             line["call_level"] = call_level(a.config)
+            line["pipeline"] = pipeline_level(a.config)
         if world == 1 and not a.no_cpu_baseline:
             workers = usable_cores() if a.cpu_pool < 0 else a.cpu_pool
             line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows, min(workers, 256))

@@ -24,7 +24,8 @@ import numpy as np
 from . import _native
 from .apap_utils import final_size, get_mesh, get_vertice, uniform_blend  # noqa: F401  (re-exported like the reference)
 
-__all__ = ["APAP", "LazyWeights", "get_mesh", "get_vertice", "final_size", "uniform_blend", "save2mat", "run_pair", "main"]
+__all__ = ["APAP", "LazyWeights", "get_mesh", "get_vertice", "final_size", "uniform_blend", "save2mat", "run_pair",
+           "run_pair_by_calls", "main"]
 
 
 class LazyWeights:
@@ -243,11 +244,22 @@ def read_config(path):
 
 
 def run_pair(src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
-             other_img=None, center_img=None, device=-1):
+             other_img=None, center_img=None, device=-1, pipeline=None):
     """Body of the reference's ``__main__`` between loading and saving
     (apap.py:238-264).  Returns ``(H_flat (m*m, 9) float64, canvas or None)``; the canvas
     is the warped other image, or - when ``center_img`` is given - the blended stitch
-    of apap.py:258-262."""
+    of apap.py:258-262.  One resident pass (:class:`cvx_proj_amd.pipeline.Pipeline`): the H grid never
+    leaves HBM between the solve, the output stage and the warp."""
+    from .pipeline import Pipeline
+    pipe = pipeline if pipeline is not None else Pipeline(device=device)
+    return pipe.run_pair(src, dst, H_global, other_shape, center_shape, mesh_size, gamma, sigma,
+                         other_img=other_img, center_img=center_img)
+
+
+def run_pair_by_calls(src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
+                      other_img=None, center_img=None, device=-1):
+    """The same through the mirror class, call by call, as the reference's ``__main__`` is written: numpy in and
+    out of every stage (the H grid crosses PCIe three times).  Kept as the yardstick of :func:`run_pair`."""
 
     class _S:
         def __init__(self, shape):
@@ -298,6 +310,7 @@ def main(argv=None):
         if v is not None:
             par[k] = v
 
+    pipeline = None
     if a.pair:
         z = np.load(a.pair)
         src, dst, Hg = z["src"], z["dst"], z["H"]
@@ -306,12 +319,20 @@ def main(argv=None):
         center_img = z["center_img"] if (a.stitch and "center_img" in z) else None
     elif a.data_root:
         from .baseline_stitch_test import CENTER_PIC_ID, visualize_feature_pairs
-        from .utils import get_no_scat_img, visualize_equalized_hist
-        center_eq = visualize_equalized_hist(a.case_idx, CENTER_PIC_ID, root=a.data_root, device=a.device)
-        other_eq = visualize_equalized_hist(a.case_idx, a.img_idx, root=a.data_root, device=a.device)
-        src, dst, Hg = visualize_feature_pairs(center_eq, other_eq, case_idx=a.case_idx, pic_id=a.img_idx, swap=True,
+        from .pipeline import Pipeline
+        from .utils import get_no_scat_img, get_path, imread
+        pipeline = Pipeline(device=a.device)
+        shapes = []
+        for idx in (CENTER_PIC_ID, a.img_idx):       # visualize_equalized_hist (apap.py:236-237), left on the device:
+            path = get_path(a.case_idx, idx, root=a.data_root)      # the reference only shows the pictures and reads their shape
+            img = imread(path)
+            if img is None:
+                raise FileNotFoundError(path)
+            pipeline.equalize(img, name=f"eq{idx}")
+            shapes.append(img.shape)
+        center_shape, other_shape = shapes
+        src, dst, Hg = visualize_feature_pairs(None, None, case_idx=a.case_idx, pic_id=a.img_idx, swap=True,
                                                root=a.data_root, device=a.device)
-        other_shape, center_shape = other_eq.shape, center_eq.shape
         other_img = center_img = None
         if a.warp or a.stitch:      # the blend uses the haze-free pictures (apap.py:245,258-262)
             center_img, other_img = get_no_scat_img(a.case_idx, a.img_idx, CENTER_PIC_ID, root=a.data_root)
@@ -329,7 +350,7 @@ def main(argv=None):
         ap.error("the reference's dataset (../diff_1) is not distributed: give --data-root, --pair or --synth")
 
     flat, warped = run_pair(src, dst, Hg, other_shape, center_shape, par["mesh_size"], par["gamma"], par["sigma"],
-                            other_img=other_img, center_img=center_img, device=a.device)
+                            other_img=other_img, center_img=center_img, device=a.device, pipeline=pipeline)
     print(f"local_homography shape: {(par['mesh_size'], par['mesh_size'], 3, 3)}")
     out_dir = f"{a.out_prefix}case{a.case_idx}"
     os.makedirs(out_dir, exist_ok=True)

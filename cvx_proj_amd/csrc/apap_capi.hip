@@ -306,11 +306,21 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     const size_t range_ints = (size_t)mesh_rows * 2 + 2;
     int rc = pipe_prepare(pool, dev, (size_t)2 * chunks + bands + 2, range_ints * sizeof(int) + 64);
     if (rc) return rc;
-    PinGuard pin_img, pin_out, pin_center, pin_H, pin_Hinv;
-    if (!pin_img.pin(img, img_bytes) || !pin_out.pin(out, out_bytes) ||
-        (center && !pin_center.pin(center, cbytes)) || !pin_H.pin(Hfwd, (size_t)cells * 9 * sizeof(float)) ||
-        (Hinv_out && !pin_Hinv.pin(Hinv_out, (size_t)cells * 9 * sizeof(float))))
+    // Only the three big buffers are pinned, and only when no two of them share a page: two registrations that
+    // overlap in a page (arrays that malloc placed back to back - numpy's `H.copy()` followed by `np.empty_like(H)`
+    // did, with the grid and its inverse pinned too) ended in a GPU fault "write access to a read-only page" on
+    // this stack.  The grid, its inverse and the edges travel as ordinary pageable copies (1.4 MB, on the kernel
+    // stream, while the image chunks are already going up).
+    auto pages_overlap = [](const void *a, size_t na, const void *b, size_t nb) {
+        const uintptr_t pa0 = (uintptr_t)a >> 12, pa1 = ((uintptr_t)a + na - 1) >> 12;
+        const uintptr_t pb0 = (uintptr_t)b >> 12, pb1 = ((uintptr_t)b + nb - 1) >> 12;
+        return pa0 <= pb1 && pb0 <= pa1;
+    };
+    if (pages_overlap(img, img_bytes, out, out_bytes) ||
+        (center && (pages_overlap(center, cbytes, out, out_bytes) || pages_overlap(center, cbytes, img, img_bytes))))
         return APAP_OK;
+    PinGuard pin_img, pin_out, pin_center;
+    if (!pin_img.pin(img, img_bytes) || !pin_out.pin(out, out_bytes) || (center && !pin_center.pin(center, cbytes))) return APAP_OK;
 
     stamp("pinned");
     const size_t work_bytes = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);

@@ -1,0 +1,159 @@
+"""The reference's ``apap.py __main__`` (apap.py:234-265) as ONE resident pass over the GPU.
+
+The mirror class of :mod:`cvx_proj_amd.apap` keeps the reference's call-by-call surface: every call
+takes numpy buffers, copies them up, runs its kernels, copies the result down.  Chained the way
+``__main__`` chains them, the H grid crosses PCIe three times (down after the solve, up again for the warp,
+up a third time for the output stage) and every stage ends in a synchronisation.  A :class:`Pipeline`
+keeps what the stages hand to each other in HBM - keypoint table, H grid, source image, canvas - enqueues
+
+    (equalise ->) (RANSAC seed ->) solve -> output stage -> warp / stitch
+
+on one HIP stream through the resident ``*_device`` entry points of ``libapap_hip.so`` and copies back
+once, at the end: the ``(m*m, 9)`` float64 array that goes into ``H3{i}_apap.mat`` and, when asked for,
+the canvas.  Same kernels, same bits as the chain of calls (``tests/test_pipeline.py``).
+
+Only the seed homography has to visit the host in between: ``final_size`` (apap_utils.py:40-73) turns it
+into the canvas geometry, mesh and vertices, which size everything after it.
+
+torch is used for device memory and the stream only.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _native
+from .apap_utils import final_size, get_mesh, get_vertice
+
+__all__ = ["Pipeline"]
+
+
+class _Shape:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class Pipeline:
+    """Resident APAP pass.  ``device``: HIP device index (-1 = current); ``ctx``: a ``_native.Context``."""
+
+    def __init__(self, device=-1, ctx=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise _native.ApapError(_native.ERR_NO_DEVICE, "Pipeline needs a HIP device; there is no CPU fallback")
+        self.torch = torch
+        self.dev = torch.device("cuda", torch.cuda.current_device() if device < 0 else device)
+        self.ctx = ctx
+        self._h = _native._h(ctx)
+        self._buf = {}              # name -> device tensor, grown on demand and reused between pairs
+        self.timeline = {}          # milliseconds of the last run_pair, by stage (host clock, after the final sync)
+
+    # ------------------------------------------------------------------ device memory
+    def _get(self, name, shape, dtype):
+        t = self._buf.get(name)
+        n = int(np.prod(shape))
+        if t is None or t.dtype != dtype or t.numel() < n:
+            t = self.torch.empty(max(n, 1), dtype=dtype, device=self.dev)
+            self._buf[name] = t
+        return t[:n].view(*shape)
+
+    def _up(self, name, array, dtype):
+        a = np.ascontiguousarray(array)
+        t = self._get(name, a.shape, dtype)
+        t.copy_(self.torch.from_numpy(a), non_blocking=True)
+        return t
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    # ------------------------------------------------------------------ stages
+    def equalize(self, img, name="eq", fetch=False):
+        """Per-channel ``cv.equalizeHist`` (utils.py:85-91) of an (h, w, c) uint8 image; the result stays on the
+        device (``fetch=True`` also returns it as numpy: the reference only ever looks at its shape and shows it)."""
+        lib = _native.lib()
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        d_in = self._up(name + "_in", img, self.torch.uint8)
+        d_out = self._get(name + "_out", img.shape, self.torch.uint8)
+        nbytes = lib.apap_equalize_workspace_bytes(ch)
+        work = self._buf.get("eq_work")
+        if work is None or work.numel() < nbytes:
+            work = self._buf["eq_work"] = self.torch.zeros(nbytes, dtype=self.torch.uint8, device=self.dev)   # zero on entry, zero on return
+        _native.check(lib.apap_equalize_hist_device(self._h, d_in.data_ptr(), img.shape[0], img.shape[1], ch, d_out.data_ptr(),
+                                                    work.data_ptr(), nbytes, self._stream()))
+        return d_out.cpu().numpy() if fetch else d_out
+
+    def seed_homography(self, src_pts, dst_pts, thresh=5.0):
+        """``cv.findHomography(src, dst, cv.RANSAC, thresh)``'s contract (baseline_stitch_test.py:42).  The
+        inlier mask and the 3 x 3 model come to the host: the canvas geometry is computed from them."""
+        return _native.find_homography_ransac(src_pts, dst_pts, thresh, device=self.dev.index, ctx=self.ctx)
+
+    def run_pair(self, src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
+                 other_img=None, center_img=None, want_grid=False):
+        """Body of the reference's ``__main__`` between loading and saving (apap.py:238-264): returns
+        ``(H_flat (m*m, 9) float64, canvas or None)`` (and the float32 H grid with ``want_grid``); the canvas is
+        the warped other image or, with ``center_img``, the blended stitch of apap.py:258-262."""
+        import time
+        torch, lib = self.torch, _native.lib()
+        t0 = time.perf_counter()
+        fw, fh, ox, oy = (int(v) for v in final_size(_Shape(center_shape), _Shape(other_shape), H_global))
+        mesh = get_mesh((fw, fh), mesh_size + 1)
+        vertices = get_vertice((fw, fh), mesh_size, (ox, oy))
+        rows, cols = vertices.shape[:2]
+        cells = rows * cols
+        q = _native.host_prepare(src, dst)                                  # apap.py:132-140 in C
+        table = _native.host_build_table(np.ascontiguousarray(src, np.float32), q["cf1"], q["cf2"])
+        denorm = _native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
+        n = table.shape[0]
+        t1 = time.perf_counter()
+        with torch.cuda.device(self.dev):
+            stream = self._stream()
+            d_table = self._up("table", table, torch.float64)
+            d_den = self._up("denorm", denorm, torch.float64)
+            d_vert = self._up("vertices", vertices.reshape(-1, 2), torch.float64)
+            d_H = self._get("H", (cells, 9), torch.float32)
+            nb = max(lib.apap_solve_workspace_bytes(self._h, n, cells), 256)
+            d_work = self._get("solve_work", (nb,), torch.uint8)
+            _native.check(lib.apap_solve_device(self._h, d_table.data_ptr(), n, d_vert.data_ptr(), cells, float(gamma), float(sigma),
+                                                d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(), nb, stream))
+            # output stage apap.py:250-264 on the resident grid
+            d_flat = self._get("flat", (cells, 9), torch.float64)
+            d_status = self._get("status", (1,), torch.int32)
+            d_status.zero_()
+            _native.check(lib.apap_flatten_device(self._h, d_H.data_ptr(), cells, d_flat.data_ptr(), d_status.data_ptr(), stream))
+            d_out = None
+            if other_img is not None:
+                img = np.ascontiguousarray(other_img, dtype=np.uint8)
+                d_img = self._up("img", img, torch.uint8)
+                d_mw = self._up("mesh_w", mesh[0], torch.float64)
+                d_mh = self._up("mesh_h", mesh[1], torch.float64)
+                d_out = self._get("canvas", (fh, fw, 3), torch.uint8)
+                wb = lib.apap_warp_workspace_bytes(rows, cols, fw, fh)
+                d_ww = self._get("warp_work", (wb,), torch.uint8)
+                if center_img is not None:
+                    cen = np.ascontiguousarray(center_img, dtype=np.uint8)
+                    d_cen = self._up("center", cen, torch.uint8)
+                    _native.check(lib.apap_stitch_device(self._h, d_img.data_ptr(), img.shape[0], img.shape[1], d_cen.data_ptr(),
+                                                         cen.shape[0], cen.shape[1], d_H.data_ptr(), rows, cols, d_mw.data_ptr(),
+                                                         mesh.shape[1], d_mh.data_ptr(), mesh.shape[1], fw, fh, ox, oy,
+                                                         d_out.data_ptr(), None, d_ww.data_ptr(), wb, d_status.data_ptr(), stream))
+                else:
+                    _native.check(lib.apap_warp_device(self._h, d_img.data_ptr(), img.shape[0], img.shape[1], d_H.data_ptr(), rows,
+                                                       cols, d_mw.data_ptr(), mesh.shape[1], d_mh.data_ptr(), mesh.shape[1], fw, fh,
+                                                       ox, oy, d_out.data_ptr(), None, d_ww.data_ptr(), wb, d_status.data_ptr(),
+                                                       stream))
+            t2 = time.perf_counter()
+            # the one trip back
+            flat = d_flat.cpu().numpy()                       # (synchronises the stream)
+            canvas = d_out.cpu().numpy() if d_out is not None else None
+            status = int(d_status.cpu()[0])
+            grid = d_H.cpu().numpy().reshape(rows, cols, 3, 3) if want_grid else None
+        t3 = time.perf_counter()
+        self.timeline = {"host_setup_ms": (t1 - t0) * 1e3, "upload_and_enqueue_ms": (t2 - t1) * 1e3,
+                         "sync_and_download_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3}
+        if status & 1:
+            raise _native.ApapSingularError(_native.ERR_SINGULAR, "Singular matrix")
+        if status & 2:
+            raise _native.ApapIndexError(_native.ERR_INDEX, "index 0 is out of bounds for axis 0 with size 0 (mesh edges do not "
+                                                             "cover the canvas)")
+        return (flat, canvas, grid) if want_grid else (flat, canvas)
