@@ -17,8 +17,10 @@ exactly K steps each, both bracketed by a barrier and a device synchronise:
 GPU); under torch.distributed.run it is one rank per GPU over RCCL.  Every run measures BOTH ways
 the path shards and puts both in the one JSON line:
 
-* ``pairs`` = the headline (``value``): every rank owns a 4K pair (config C3) - independent
+* the headline (``value``, ``pair_per_rank``): every rank owns a 4K pair (config C3) - independent
   units, no data-path collective, weak scaling;
+* ``pairs`` = BASELINE config 5 as it is written: 64 independent 4K pairs at 100 x 100, dealt over the
+  ranks, each rank's share in ONE batched launch, no collective - strong scaling;
 * ``cells`` = ONE pair of ``--cells-config`` (C4: 8K, 5000 keypoints, 400 x 400 mesh) with its mesh
   rows sharded over the ranks by cvx_proj_amd.dist.ShardedSolver: table broadcast from rank 0 once
   per pair, per-rank solve, all-gather of the H grid; warp by canvas-row bands + all-gather - strong
@@ -165,6 +167,38 @@ class Resident:
                                            p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
                                            self.out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
                                            self.status.data_ptr(), ctypes.c_void_p(stream)))
+
+
+class PairBatch:
+    """BASELINE config 5: independent pairs sharing one mesh shape, this rank's share solved in ONE batched
+    launch (blockIdx.z = pair); keypoint tables, de-normalisation blocks, vertices and the H grids resident."""
+
+    def __init__(self, cfg, indices, dev, ctx=None):
+        self.ctx = N._h(ctx)
+        self.batch = len(indices)
+        tabs, dens = [], []
+        pair = None
+        for k in indices:
+            pair = config_pair(cfg, with_image=False, seed_offset=k)
+            q = N.host_prepare(pair.src, pair.dst)
+            tabs.append(N.host_build_table(pair.src, q["cf1"], q["cf2"]))
+            dens.append(N.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"]))
+        self.pair = pair
+        self.n = len(pair.src)
+        self.rows, self.cols = pair.vertices.shape[:2]
+        self.cells = self.rows * self.cols
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.table, self.den = t(np.stack(tabs)), t(np.stack(dens))
+        self.vert = t(pair.vertices.reshape(-1, 2))        # every pair of a configuration has the same canvas, hence mesh
+        self.H = torch.zeros((self.batch * self.cells, 9), dtype=torch.float32, device=dev)
+        self.work_bytes = max(N.lib().apap_solve_batch_workspace_bytes(self.ctx, self.n, self.cells, self.batch), 256)
+        self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=dev)
+
+    def solve(self, stream):
+        p = self.pair
+        N.check(N.lib().apap_solve_batch_device(self.ctx, self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, self.cells,
+                                                p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(), self.batch,
+                                                self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -405,6 +439,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cells", action="store_true", help="skip the `cells` (strong-scaling) object")
     ap.add_argument("--no-call-level", action="store_true")
+    ap.add_argument("--no-c5", action="store_true", help="skip the `pairs` object (BASELINE config 5: 64 pairs over the ranks)")
+    ap.add_argument("--c5-pairs", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1,
                     help="solve this many independent pairs per step in ONE batched launch (config C5 style); "
                          "the warp half then runs once per pair")
@@ -579,6 +615,25 @@ def main():
         from_idle.append(time.perf_counter() - t0)
     t_idle = sorted(from_idle)[1]
 
+    # ------------------------------------------------------------------ pairs as BASELINE config 5 states them
+    c5_obj = None
+    if not a.no_c5:
+        total_pairs = a.c5_pairs
+        mine = list(range(rank, total_pairs, world))          # dealt round-robin: 64 / N per rank
+        pb = PairBatch("C5", mine, dev, ctx=ctx) if mine else None
+        if pb is not None:
+            condition(lambda: pb.solve(stream))
+            for _ in range(a.warmup):
+                pb.solve(stream)
+        t_c5 = timed((lambda: pb.solve(stream)) if pb is not None else (lambda: None), a.steps)
+        cells_c5 = CONFIGS["C5"][3] ** 2
+        c5_obj = {"workload": f"C5: {total_pairs} independent 3840x2160 pairs, 2000 correspondences, 100x100 mesh each; "
+                              f"{len(mine)} per rank in ONE batched launch", "world_size": world, "scaling": "strong",
+                  "value": total_pairs * cells_c5 * a.steps / t_c5, "unit": "homographies/s",
+                  "solve_ms_per_step": t_c5 / a.steps * 1e3, "pairs_per_s": total_pairs * a.steps / t_c5,
+                  "pairs_per_rank": len(mine), "collectives_per_step": "none (independent pairs)"}
+        del pb
+
     # ------------------------------------------------------------------ cells: one pair sharded
     cells_obj = None
     if not a.no_cells:
@@ -630,8 +685,9 @@ def main():
                                 "note": "row bands left where they are computed (no collective): the part of the warp that "
                                         "shards; SURVEY.md 8e expects the gathered form to be transfer-dominated"},
             "table_broadcast_ms": t_bcast * 1e3, "first_warp_incl_image_broadcast_ms": t_first_warp * 1e3,
-            "collectives_per_step": "solve: 1 all-gather of the H grid (36 B per cell); warp: 1 all-gather of the canvas bands"
-                                    if world > 1 else "none",
+            "collectives_per_step": "solve: the H grid (36 B per cell) in 2 all-gathers, the first beside the second half's "
+                                    "kernels; warp: 1 all-gather of the canvas bands" if world > 1 else "none",
+            "collectives_overlapped": bool(cs.overlap),
             "rank0_cells": cs.my_cells, "kernels_ms": ckern,
             "roofline": None if c_ach is None else {
                 "kernel": "k_assemble (rank 0's shard)", "bound": "mfma", "achieved": c_ach, "peak": PEAK_FP64_TFLOPS,
@@ -644,6 +700,10 @@ def main():
         t_k1 = kern["assemble"] * 1e-3
         achieved = flops / t_k1 / 1e12
         resolved = "mfma" if a.variant == "auto" else a.variant      # auto = mfma (apap_kernels.hip plan_solve)
+        # small meshes under AUTO take ONE fused launch (K1 + K2): it is timed in the `assemble` slot and `eigen` stays empty
+        fused = a.variant == "auto" and res.cells * res.batch <= ctx.get("fused_max_cells")
+        if fused:
+            kern["solve_small (K1 + K2 fused, reported in the assemble slot)"] = kern["assemble"]
         # HBM bytes per launch from the PMC counters, collected in separate rocprofv3 passes
         # (tools/profile.sh) and committed under profiles/: (2 x FETCH_SIZE + WRITE_SIZE) KiB,
         # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane reads.
@@ -657,7 +717,7 @@ def main():
         out_pixels = pair.final_w * pair.final_h
         nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu())
         warp_bytes = 6 * nz + 3 * (out_pixels - nz)
-        pairs_obj = {"workload": f"{a.config} x {world} (one pair per rank)", "world_size": world, "scaling": "weak",
+        per_rank_obj = {"workload": f"{a.config} x {world} (one pair per rank)", "world_size": world, "scaling": "weak",
                      "value": units_solve * a.steps / t_solve, "unit": "homographies/s",
                      "solve_ms_per_step": t_solve / a.steps * 1e3,
                      "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
@@ -677,7 +737,8 @@ def main():
             "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
                      "ms_per_step": t_warp / a.steps * 1e3},
             "solve_ms_per_step": t_solve / a.steps * 1e3,
-            "pairs": pairs_obj,
+            "pairs": c5_obj,
+            "pair_per_rank": per_rank_obj,
             "cells": cells_obj,
             "stitch": {
                 "value": pair.final_w * pair.final_h * a.steps / t_stitch / 1e6, "unit": "Mpix/s (rank 0)",
@@ -698,9 +759,13 @@ def main():
                 "note": "device half of the seed homography (4-point hypotheses, 5 px), baseline_stitch_test.py:42; "
                         "three small latency-bound kernels; extra, not in `value`"},
             "kernels_ms": kern,
-            "roofline": {"kernel": "k_assemble_" + resolved, "bound": "mfma",
+            "roofline": {"kernel": "k_solve_small (fused K1 + K2: the K2 tail is inside the time, only K1's flops are counted)"
+                                   if fused else "k_assemble_" + resolved, "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "traffic_vs_algorithmic": None if traffic is None else traffic / (36.0 * res.cells * res.batch + 16.0 * res.n),
+                         "traffic_note": "the moment slab K1 writes and K2 reads back (30 doubles per cell and keypoint split) is "
+                                         "~17x the algorithmic 36 B per cell + 16 B per keypoint; at ~165 GB/s it is 2 % of HBM",
                          "hbm_gbs": None if traffic is None else traffic / t_k1 / 1e9,
                          "note": "fp64 work, issue-bound: no vector instruction co-executes with an f64 MFMA on gfx950 "
                                  "(profiles/r02_coexec.txt), so the datasheet's single 78.6 TF figure covers the 32 "

@@ -28,7 +28,7 @@ VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1,
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 # options of a context (include/apap_hip.h)
 OPT_SOLVER_VARIANT, OPT_EIGEN_SOLVER, OPT_CAREFUL, OPT_PROFILE, OPT_WANT_WAVES, OPT_WARP_ROWS, OPT_WEIGHT_CHUNK_KB, \
-    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE = range(10)
+    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS = range(11)
 
 
 class ApapError(RuntimeError):
@@ -180,7 +180,8 @@ class Context:
 
     _NAMES = {"variant": OPT_SOLVER_VARIANT, "eigen": OPT_EIGEN_SOLVER, "careful": OPT_CAREFUL, "profile": OPT_PROFILE,
               "want_waves": OPT_WANT_WAVES, "warp_rows": OPT_WARP_ROWS, "weight_chunk_kb": OPT_WEIGHT_CHUNK_KB,
-              "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST, "overlap_pcie": OPT_OVERLAP_PCIE}
+              "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST, "overlap_pcie": OPT_OVERLAP_PCIE,
+              "plan_cells": OPT_PLAN_CELLS}
 
     def set(self, name, value):
         check(lib().apap_ctx_set_option(self._h, self._NAMES[name], int(value)))

@@ -967,7 +967,10 @@ template <int K>
 __device__ __forceinline__ void givens_insert(double (&R)[45], double (&r)[9]) {
     const double a = R[tri(K, K)], b = r[K];
     const double big = fmax(fabs(a), fabs(b));
-    const bool rot = (b != 0.0) && (big < 1.797e308);  // false for NaN/inf rows: they are dropped
+    // no rotation for an infinite entry (the scaling below would divide inf by inf).  A NaN entry is NOT filtered:
+    // fmax ignores it, the rotation goes ahead and R turns NaN - like the reference's SVD of a matrix with a NaN
+    // row (apap.py:159-161), whose cell is NaN too; such rows only come from non-finite keypoints.
+    const bool rot = (b != 0.0) && (big < 1.797e308);
     const int e = rot ? __builtin_amdgcn_frexp_exp(big) : 0;
     const double sa = __builtin_ldexp(a, -e), sb = __builtin_ldexp(b, -e);
     const double t = sqrt(fma(sa, sa, sb * sb));
@@ -2417,7 +2420,7 @@ ProfScope::~ProfScope() {
     ctx_->spans.push_back(ProfSpan{slot_, a_, b_});
 }
 
-SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves) {
+SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, int plan_cells) {
     SolvePlan p{};
     if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_MFMA;  // measured faster on C2-C4, DESIGN.md
     p.variant = variant;
@@ -2434,7 +2437,9 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves) {
     // APAP_VARIANT_MFMA4X2), the VALU kernel's is 4 waves on 4 tiles
     const int waves_per_2tiles = variant == APAP_VARIANT_MFMA || variant == APAP_VARIANT_MFMA4 ? 8
                                  : variant == APAP_VARIANT_MFMA4X2 ? 4 : 2;
-    while (splits < 32 && (long long)p.cell_tiles * batch * waves_per_2tiles * splits < 2 * want_waves && n / (splits * 2) >= kChunk) splits *= 2;
+    // APAP_OPT_PLAN_CELLS: the splits one pair of that many cells would get, whatever this launch holds
+    const long long plan_tiles = plan_cells > 0 ? (plan_cells + kWave - 1) / kWave : (long long)p.cell_tiles * batch;
+    while (splits < 32 && plan_tiles * waves_per_2tiles * splits < 2 * want_waves && n / (splits * 2) >= kChunk) splits *= 2;
     int pps = (n + splits - 1) / splits;
     pps = (pps + kChunk - 1) / kChunk * kChunk;
     p.splits = (n + pps - 1) / pps;  // no empty split
@@ -2475,7 +2480,8 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_WANT_WAVES: ok = value >= 1; break;
         case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 2 || value == 4 || value == 8; break;
         case APAP_OPT_WEIGHT_CHUNK_KB: ok = value >= 1; break;
-        case APAP_OPT_FUSED_MAX_CELLS: ok = value >= 0; break;
+        case APAP_OPT_FUSED_MAX_CELLS:
+        case APAP_OPT_PLAN_CELLS: ok = value >= 0; break;
         case APAP_OPT_WARP_FAST:
         case APAP_OPT_OVERLAP_PCIE: ok = value == 0 || value == 1; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
@@ -2514,7 +2520,7 @@ int apap_ctx_profile_read(apap_ctx *ctx, float *ms, int *launches) {
 
 size_t apap_solve_batch_workspace_bytes(apap_ctx *ctx, int n, int cells, int batch) {
     if (n < 1 || cells < 1 || batch < 1) return 0;
-    return apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES)).moment_bytes * (size_t)batch;
+    return apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES), apap::opt(ctx, APAP_OPT_PLAN_CELLS)).moment_bytes * (size_t)batch;
 }
 
 size_t apap_solve_workspace_bytes(apap_ctx *ctx, int n, int cells) { return apap_solve_batch_workspace_bytes(ctx, n, cells, 1); }
@@ -2526,7 +2532,7 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: null device pointer");
     if (n < 1 || cells < 1 || batch < 1 || batch > 65535 || vertices_stride < 0)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: n=%d cells=%d batch=%d", n, cells, batch);
-    const apap::SolvePlan p = apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES));
+    const apap::SolvePlan p = apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES), apap::opt(ctx, APAP_OPT_PLAN_CELLS));
     if (work_bytes < p.moment_bytes * (size_t)batch)
         return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes,
                           p.moment_bytes * (size_t)batch);
@@ -2545,7 +2551,9 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
     const int careful = apap::opt(ctx, APAP_OPT_CAREFUL);
     // Small meshes (AUTO only): one fused launch, 16 cells per block.  Up to 4096 cells in all the
     // blocks fit the chip in about one round at the fused kernel's one wave per SIMD.
-    if (apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO && (long long)cells * batch <= apap::opt(ctx, APAP_OPT_FUSED_MAX_CELLS)) {
+    const int plan_cells = apap::opt(ctx, APAP_OPT_PLAN_CELLS);
+    if (apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO &&
+        (plan_cells > 0 ? (long long)plan_cells : (long long)cells * batch) <= apap::opt(ctx, APAP_OPT_FUSED_MAX_CELLS)) {
         ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);   // reported under the K1 slot; the K2 slot stays empty
         const dim3 grid((cells + 15) / 16, 1, batch);
         if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)

@@ -5,9 +5,9 @@ The path shards in two ways:
 
 * **cells of one pair** (config C4): every mesh cell is independent given the keypoint
   table.  Rank 0 prepares the table on its host and *broadcasts* it (n x 256 B - 1.3 MB at
-  n = 5000); each rank solves a contiguous block of mesh rows; one *all-gather* assembles
-  the H grid (36 B per cell - 5.8 MB at 400 x 400, 720 KB per rank: on fully connected xGMI
-  that is one hop and latency-bound, so it is a single un-bucketed collective).
+  n = 5000); each rank solves a contiguous block of mesh rows in two launches; the *all-gather*
+  of the first half of the H grid (36 B per cell - 5.8 MB at 400 x 400, 720 KB per rank: on fully
+  connected xGMI that is one hop and latency-bound) runs while the second half is computed.
 * **independent pairs** (config C5): pairs are dealt round-robin to the ranks; no
   collective on the data path, one gather of the H grids at the end.
 
@@ -37,17 +37,20 @@ def row_partition(rows, world):
     return out
 
 
-def hip_solve(table, denorm, vertices, gamma, sigma, ctx=None):
-    """Default ``solve_fn``: resident-data C-ABI call on the tensors' device."""
+def hip_solve(table, denorm, vertices, gamma, sigma, ctx=None, out=None, work=None):
+    """Default ``solve_fn``: resident-data C-ABI call on the tensors' device.  ``out`` (>= cells x 9 float32)
+    and ``work`` (uint8 scratch) are reused when given and large enough - a solver that runs every step keeps
+    them - else allocated."""
     if not table.is_cuda:
         raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_solve needs CUDA/HIP tensors; there is no CPU fallback")
     cells = vertices.shape[0]
     n = table.shape[0]
-    H = torch.empty((cells, 9), dtype=torch.float32, device=table.device)
+    H = out[:cells] if out is not None and out.shape[0] >= cells else torch.empty((cells, 9), dtype=torch.float32, device=table.device)
     if cells == 0:
         return H
     nbytes = max(_native.lib().apap_solve_workspace_bytes(_native._h(ctx), n, cells), 256)
-    work = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+    if work is None or work.numel() < nbytes:
+        work = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
     stream = torch.cuda.current_stream(table.device).cuda_stream
     _native.check(_native.lib().apap_solve_device(_native._h(ctx), table.data_ptr(), n, vertices.data_ptr(), cells, float(gamma),
                                                   float(sigma), denorm.data_ptr(), H.data_ptr(), work.data_ptr(),
@@ -55,15 +58,18 @@ def hip_solve(table, denorm, vertices, gamma, sigma, ctx=None):
     return H
 
 
-def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_begin, row_count, out_band, shape, ctx=None):
+def hip_warp_rows(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, row_begin, row_count, out_band, shape, ctx=None,
+                  work=None, status=None):
     """Default ``warp_fn``: resident-data C-ABI call warping canvas rows
-    ``[row_begin, row_begin + row_count)`` into ``out_band``."""
+    ``[row_begin, row_begin + row_count)`` into ``out_band``.  ``work`` / ``status`` are reused when given."""
     if not img.is_cuda:
         raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_warp_rows needs CUDA/HIP tensors; there is no CPU fallback")
     rows, cols = shape
     nbytes = _native.lib().apap_warp_workspace_bytes(rows, cols, final_w, final_h)
-    work = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
-    status = torch.zeros(1, dtype=torch.int32, device=img.device)
+    if work is None or work.numel() < nbytes:
+        work = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=img.device)
     stream = torch.cuda.current_stream(img.device).cuda_stream
     _native.check(_native.lib().apap_warp_rows_device(
         _native._h(ctx), img.data_ptr(), img.shape[0], img.shape[1], H.data_ptr(), rows, cols, mesh_w.data_ptr(), mesh_w.numel(),
@@ -97,22 +103,56 @@ class ShardedSolver:
     the caller has not).  ``solve()`` = local solve of this rank's rows + all-gather of the H
     grid; afterwards ``self.H`` holds the full grid on every rank (what a following sharded
     warp needs for its own rows, and what rank 0 writes).
+
+    The rank's rows are solved in TWO launches and the first half's all-gather runs while the second half is
+    being computed (``overlap=True``): at 8 ranks a C4 shard is ~170 us of kernels, a latency-bound collective of
+    20-50 us would otherwise be 10-25 % of the step.  Every buffer of the step (shard grids, gather buffers,
+    scratch, status) is allocated here, once.
+
+    ``same_bits=True`` makes the shards sum every cell's keypoints in the order the whole mesh would on one GPU
+    (``APAP_OPT_PLAN_CELLS``): the gathered grid then equals the single-GPU grid bit for bit for any number of
+    ranks.  Off by default: a shard is a small launch, and the finer keypoint splits it would otherwise get are
+    what fills the GPU - the grids of the two settings differ by float64 summation order only (a float32 value in
+    a few thousand may round the other way; the 1e-4 px parity bar is six orders of magnitude above that).
     """
 
-    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows, ctx=None):
+    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows, ctx=None, overlap=True,
+                 same_bits=False):
         self.pair, self.dev, self.dist, self.solve_fn, self.warp_fn = pair, dev, dist, solve_fn, warp_fn
-        # a _native.Context (options, profiling) handed to the default HIP compute functions
-        self._kw = {"ctx": ctx} if ctx is not None else {}
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
         self.rows, self.cols = pair.vertices.shape[:2]
         self.cells_total = self.rows * self.cols
+        if same_bits and solve_fn is hip_solve:
+            if ctx is None:
+                ctx = _native.Context()
+            ctx.set("plan_cells", self.cells_total)
+        # a _native.Context (options, profiling) handed to the default HIP compute functions
+        self._ctx = ctx
+        self._kw = {"ctx": ctx} if ctx is not None else {}
+        self.overlap = bool(overlap) and self.world > 1
         self.n = len(pair.src)
         self.parts = row_partition(self.rows, self.world)
         self.max_rows = max(b - a for a, b in self.parts)
         a, b = self.parts[self.rank]
         self.my_rows = (a, b)
-        self.vert = torch.from_numpy(np.ascontiguousarray(pair.vertices[a:b].reshape(-1, 2))).to(dev)
+        # the two launches of a rank: rows [a, m) and [m, b)
+        halves = [(ra, ra + (rb - ra + 1) // 2, rb) for ra, rb in self.parts] if self.overlap else [(ra, rb, rb) for ra, rb in self.parts]
+        self._pieces = [[(ra, rm) for ra, rm, rb in halves], [(rm, rb) for ra, rm, rb in halves]]
+        verts = np.ascontiguousarray(pair.vertices.reshape(-1, 2))
+        self._vert, self._mine, self._gather, self._dst, self._src = [], [], [], [], []
+        for piece in self._pieces:
+            pa, pb = piece[self.rank]
+            pad = max(qb - qa for qa, qb in piece) * self.cols          # cells per rank in this piece, padded to the largest
+            self._vert.append(torch.from_numpy(verts[pa * self.cols:pb * self.cols]).to(dev))
+            self._mine.append(torch.zeros((max(pad, 1), 9), dtype=torch.float32, device=dev))
+            self._gather.append(torch.zeros((self.world, max(pad, 1), 9), dtype=torch.float32, device=dev))
+            # where the gathered rows go: rank r's valid cells -> its rows of the grid, the padding is dropped
+            dst = np.concatenate([np.arange(qa * self.cols, qb * self.cols) for qa, qb in piece]) if self.cells_total else np.zeros(0, int)
+            src = np.concatenate([r * max(pad, 1) + np.arange((qb - qa) * self.cols) for r, (qa, qb) in enumerate(piece)])
+            self._dst.append(torch.from_numpy(dst.astype(np.int64)).to(dev))
+            self._src.append(torch.from_numpy(src.astype(np.int64)).to(dev))
+        self.vert = torch.from_numpy(verts[a * self.cols:b * self.cols]).to(dev)
         # rank 0 owns the host set-up; the others receive the result
         self.table = torch.zeros((self.n, _native.TABLE_STRIDE), dtype=torch.float64, device=dev)
         self.denorm = torch.zeros(_native.DENORM_DOUBLES, dtype=torch.float64, device=dev)
@@ -121,12 +161,15 @@ class ShardedSolver:
             self.table.copy_(torch.from_numpy(_native.host_build_table(pair.src, q["cf1"], q["cf2"])))
             self.denorm.copy_(torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])))
         self.H = torch.zeros((self.cells_total, 9), dtype=torch.float32, device=dev)
-        self._gather = torch.zeros((self.world, self.max_rows * self.cols, 9), dtype=torch.float32, device=dev)
-        self._mine = torch.zeros((self.max_rows * self.cols, 9), dtype=torch.float32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.cells = self.cells_total
         self.my_cells = (b - a) * self.cols          # what this rank's kernels work on
         self._inputs_sent = False
+        self._solve_kw = dict(self._kw)
+        if solve_fn is hip_solve:                   # the engine's scratch: sized once for the larger launch
+            nb = max([max(_native.lib().apap_solve_workspace_bytes(_native._h(ctx), self.n, v.shape[0]), 256) if v.shape[0] else 256
+                      for v in self._vert])
+            self._solve_kw["work"] = torch.empty(nb, dtype=torch.uint8, device=dev)
 
     def broadcast_inputs(self):
         """Keypoint table (n x 256 B) and de-normalisation block from rank 0 to every rank:
@@ -137,23 +180,36 @@ class ShardedSolver:
             d.broadcast(self.denorm, src=0)
         self._inputs_sent = True
 
+    def _solve_piece(self, k):
+        """Launch piece k of this rank's rows into its (padded) shard buffer."""
+        vert, mine = self._vert[k], self._mine[k]
+        kw = dict(self._solve_kw)
+        if self.solve_fn is hip_solve:
+            kw["out"] = mine
+        res = self.solve_fn(self.table, self.denorm, vert, self.pair.gamma, self.pair.sigma, **kw)
+        if res.data_ptr() != mine.data_ptr() and vert.shape[0]:
+            mine[:vert.shape[0]].copy_(res)
+        return mine
+
     def solve(self, stream=None):
         d = self.dist
         if not self._inputs_sent:
             self.broadcast_inputs()
-        a, b = self.my_rows
-        mine = self.solve_fn(self.table, self.denorm, self.vert, self.pair.gamma, self.pair.sigma, **self._kw)
         if d is None or self.world == 1:
-            self.H.copy_(mine)
+            mine = self._solve_piece(0)
+            self.H.copy_(mine[:self.cells_total])
             return self.H
-        if all(rb - ra == b - a for ra, rb in self.parts):
-            # equal shards (e.g. 400 mesh rows over 8 ranks): gather straight into the grid
-            d.all_gather_into_tensor(self.H, mine)
-            return self.H
-        self._mine[:(b - a) * self.cols].copy_(mine)
-        d.all_gather_into_tensor(self._gather.view(-1, 9), self._mine)
-        for r, (ra, rb) in enumerate(self.parts):      # drop the padding of uneven shards
-            self.H[ra * self.cols:rb * self.cols].copy_(self._gather[r, :(rb - ra) * self.cols])
+        pending = []
+        for k in range(2 if self.overlap else 1):
+            mine = self._solve_piece(k)
+            # async: the collective is ordered after this piece's kernels and runs beside the next piece's
+            pending.append(d.all_gather_into_tensor(self._gather[k].view(-1, 9), mine, async_op=True))
+        for k, w in enumerate(pending):
+            w.wait()
+            g = self._gather[k].view(-1, 9)
+            if self._src[k].numel() != g.shape[0]:      # uneven shards: drop the padding
+                g = g.index_select(0, self._src[k])
+            self.H.index_copy_(0, self._dst[k], g)
         return self.H
 
     def _warp_setup(self):
@@ -171,8 +227,17 @@ class ShardedSolver:
             d.broadcast(self.img, src=0)
         self.mesh_w = torch.from_numpy(np.ascontiguousarray(p.mesh[0])).to(self.dev)
         self.mesh_h = torch.from_numpy(np.ascontiguousarray(p.mesh[1])).to(self.dev)
+        if self.warp_fn is hip_warp_rows:       # the engine's scratch and status word: once
+            nb = _native.lib().apap_warp_workspace_bytes(self.rows, self.cols, p.final_w, p.final_h)
+            self._warp_kw = dict(self._kw, work=torch.empty(nb, dtype=torch.uint8, device=self.dev), status=self.status)
+        else:
+            self._warp_kw = dict(self._kw)
         self._band = torch.zeros((self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
         self._bands = torch.zeros((self.world, self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
+        dst = np.concatenate([np.arange(ra, rb) for ra, rb in self.bands])
+        src = np.concatenate([r * self.max_band + np.arange(rb - ra) for r, (ra, rb) in enumerate(self.bands)])
+        self._band_dst = torch.from_numpy(dst.astype(np.int64)).to(self.dev)
+        self._band_src = torch.from_numpy(src.astype(np.int64)).to(self.dev)
         self.out = torch.zeros((p.final_h, p.final_w, 3), dtype=torch.uint8, device=self.dev)
 
     def warp(self, stream=None, gather=True):
@@ -189,7 +254,7 @@ class ShardedSolver:
         a, b = self.bands[self.rank]
         single = d is None or self.world == 1
         st = self.warp_fn(self.img, self.H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
-                          self.out if single else self._band, (self.rows, self.cols), **self._kw)   # one rank: straight into the canvas
+                          self.out if single else self._band, (self.rows, self.cols), **self._warp_kw)   # one rank: straight into the canvas
         if st is not None:
             self.status = st
         if single:
@@ -200,8 +265,7 @@ class ShardedSolver:
             d.all_gather_into_tensor(self.out, self._band[:b - a])
             return self.out
         d.all_gather_into_tensor(self._bands.view(-1, p.final_w, 3), self._band)
-        for r, (ra, rb) in enumerate(self.bands):
-            self.out[ra:rb].copy_(self._bands[r, :rb - ra])
+        self.out.index_copy_(0, self._band_dst, self._bands.view(-1, p.final_w, 3).index_select(0, self._band_src))   # drop the padding
         return self.out
 
 

@@ -118,7 +118,12 @@ typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_OVERLAP_PCIE 9    /* 1 (default): apap_local_warp / apap_local_stitch pin the caller's buffers for the call
                                       and overlap the image upload, the warp (in row bands) and the canvas download on
                                       three streams; 0: one copy up, one kernel, one copy down                         */
-#define APAP_OPT_COUNT 10
+#define APAP_OPT_PLAN_CELLS 10      /* 0 (default): the solve picks its kernel (fused small-mesh launch or K1 + K2) and its
+                                      keypoint splits from THIS call's cells x batch.  c > 0: as for ONE pair of c cells,
+                                      whatever the call holds - a shard of a mesh (cvx_proj_amd/dist.py) then sums every
+                                      cell's keypoints in the order the whole mesh would on one GPU: the same bits for any
+                                      number of ranks, at the price of fewer, larger blocks per GPU                      */
+#define APAP_OPT_COUNT 11
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);

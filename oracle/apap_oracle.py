@@ -261,7 +261,10 @@ def local_homography_pool(src_point, dst_point, vertices, gamma, sigma, cells, w
     ctx = mp.get_context("spawn")      # never fork a process that has initialised the GPU
     ready = ctx.Value("i", 0)
     with ctx.Pool(workers, initializer=_pool_init, initargs=(ready,)) as pool:
+        deadline = time.perf_counter() + 60.0
         while ready.value < workers:   # every worker has started and imported this module (numpy with it)
+            if time.perf_counter() > deadline:      # a worker died in its import or initializer: do not hang the caller
+                raise RuntimeError(f"local_homography_pool: only {ready.value} of {workers} workers started within 60 s")
             time.sleep(0.01)
         t0 = time.perf_counter()
         parts = pool.map(_pool_worker, [(src_point, dst_point, vertices, gamma, sigma, c) for c in chunks if c])

@@ -31,7 +31,11 @@ def main():
     H = s.solve().cpu().numpy().copy()
     canvas = s.warp().cpu().numpy().copy()
     H2 = s.solve().cpu().numpy()                          # a second solve does not broadcast again and gives the same grid
-    assert np.array_equal(H, H2)
+    assert np.array_equal(H, H2) and s.overlap
+    s_one = ShardedSolver(p, dev, dist, overlap=False)    # one launch + one gather per rank
+    assert np.array_equal(s_one.solve().cpu().numpy(), H)
+    s_bits = ShardedSolver(p, dev, dist, same_bits=True)  # the whole mesh's summation order on every shard
+    H_bits = s_bits.solve().cpu().numpy().copy()
     band = s.warp(gather=False).cpu().numpy()             # the canvas left distributed: this rank's rows only
     lo, hi = s.bands[rank]
     assert np.array_equal(band, canvas[lo:hi])
@@ -41,7 +45,7 @@ def main():
     dist.all_gather_object(gathered, (H.tobytes(), canvas.tobytes()))
     assert all(g == gathered[0] for g in gathered), "ranks disagree on the gathered grid / canvas"
     if rank == 0:
-        np.savez(out_path, H=H, canvas=canvas, parts=np.array(s.parts), bands=np.array(s.bands),
+        np.savez(out_path, H=H, H_same_bits=H_bits, canvas=canvas, parts=np.array(s.parts), bands=np.array(s.bands),
                  status=int(s.status.cpu()[0]), grids=np.stack(grids))
     dist.barrier()
     dist.destroy_process_group()

@@ -74,8 +74,12 @@ def worker(rank, world, port, rows, q):
         s = ShardedSolver(p, torch.device("cpu"), dist, solve_fn=oracle_solve, warp_fn=oracle_warp_rows)
         if rank != 0:
             assert float(s.table.abs().sum()) == 0.0            # only rank 0 holds the table before solve()
+        assert s.overlap                                         # two launches per rank, the first gather beside the second
         H = s.solve().numpy().copy()
         assert float(s.table.abs().sum()) > 0.0                  # broadcast arrived
+        s1 = ShardedSolver(p, torch.device("cpu"), dist, solve_fn=oracle_solve, warp_fn=oracle_warp_rows, overlap=False)
+        assert not s1.overlap and np.array_equal(s1.solve().numpy(), H)      # one launch + one gather: the same grid
+        assert np.array_equal(s.solve().numpy(), H)               # and again: the buffers are reused
         canvas = s.warp().numpy().copy()                         # image broadcast + banded warp + all-gather
         assert s.bands[0][0] == 0 and s.bands[-1][1] == p.final_h
         lo, hi = s.bands[rank]

@@ -68,7 +68,8 @@ def test_config_grid_vs_reference(native, golden, variant, cfg, name):
     assert W is None
     d = report(cfg, H, g["H_ref"], p.src[:128])
     assert d.max() < RMSE_BAR
-    assert np.mean(H != g["H_ref"]) < 0.01      # in practice bit-identical almost everywhere
+    # DESIGN.md section 4 claims 0 differing float32 values for every K1 x K2 combination: the test is as tight as the claim
+    assert np.array_equal(H, g["H_ref"]), f"{int((H != g['H_ref']).sum())} float32 values differ from the reference's grid"
 
 
 def test_weights_checksum_c2(native, golden):
@@ -390,7 +391,7 @@ def test_c4_full_size_solve_vs_oracle_subset(native, golden):
     assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
     every = int(g["keep_rows_every"])
     d_ref = report("C4 rows ::8 vs reference", H[::every], g["H_ref"], p.src[:128])
-    assert d_ref.max() < RMSE_BAR and np.mean(H[::every] != g["H_ref"]) < 0.01
+    assert d_ref.max() < RMSE_BAR and np.array_equal(H[::every], g["H_ref"])
     sub = p.vertices[::5]
     H_ref, _ = O.local_homography_fast(p.src, p.dst, sub, p.gamma, p.sigma)
     d = report("C4 rows ::5", H[::5], H_ref, p.src[:128])

@@ -158,7 +158,6 @@ def test_c4_warp_rows_vs_reference(golden):
     every, keep = int(g["warp_rows_every"]), int(g["keep_rows_every"])
     rows = list(range(0, p.final_h, every))
     cell_rows = O.cell_lookup(p.final_h, p.mesh[1])[rows]
-    assert (cell_rows % keep == 0).all() or True      # only mesh rows kept in the fixture can be checked
     usable = [r for r, c in zip(rows, cell_rows) if c % keep == 0]
     assert len(usable) >= 2
     hinv = np.tile(np.eye(3, dtype=np.float32), (400, 400, 1, 1))
