@@ -2171,7 +2171,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
-    const int y_first = row_begin + ((int)blockIdx.y * 4 + wave) * kRows;
+    const int y_first = row_begin + ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * kRows;
     const int y_end = min(y_first + kRows, row_begin + row_count);
     if (j0 >= final_w || y_first >= y_end) return;
     const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
@@ -2184,7 +2184,11 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     float dxf[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+#ifdef APAP_K3_ABL_ARITHCOL   // experiment (wrong pixels at cell edges): cell column without waiting for the table
+        col[k] = (unsigned)(((unsigned long long)(unsigned)min(j0 + k, final_w - 1) * (unsigned)mesh_cols) / (unsigned)final_w);
+#else
         col[k] = cev[k] & 0xffffu;
+#endif
         dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
     // row entries: wave-uniform, scalar loads
@@ -2193,7 +2197,11 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const uint2 e = frow[(unsigned)min(y_first + t, y_end - 1)];
+#ifdef APAP_K3_ABL_ARITHCOL
+        rr[t] = (unsigned)(((unsigned long long)(unsigned)min(y_first + t, y_end - 1) * (unsigned)mesh_rows) / (unsigned)final_h);
+#else
         rr[t] = __builtin_amdgcn_readfirstlane(e.x);
+#endif
         dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.y));
     }
     unsigned off[kRows][4];
@@ -2263,6 +2271,9 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
         for (int t = 0; t < kRows; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) any |= doubt[t][k];
+#ifdef APAP_K3_ABL_NODOUBT     // experiment (wrong pixels): what the exact path costs
+        any = 0;
+#endif
         if (any != 0) {
             unsigned bits = 0;
 #pragma unroll
@@ -2722,14 +2733,18 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
     if (strips && fast_tables && apap::opt(ctx, APAP_OPT_WARP_FAST) && final_w / mesh_cols <= 128 && final_h / mesh_rows <= 128) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;
-        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
+#ifndef APAP_K3_BLOCK
+#define APAP_K3_BLOCK 256
+#endif
+        constexpr int kWpb = APAP_K3_BLOCK / 64;      // waves (= strips) per block
+        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + kWpb * rows - 1) / (kWpb * rows)));
 #define APAP_LAUNCH_FAST(R)                                                                                          \
     if (d_center)                                                                                                    \
-        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
+        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out, d_center,           \
                            center_h, center_w, row_begin, row_count);                                                \
     else                                                                                                             \
-        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
+        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
                            (const uint8_t *)nullptr, 0, 0, row_begin, row_count)
         if (rows == 4) { APAP_LAUNCH_FAST(4); }
