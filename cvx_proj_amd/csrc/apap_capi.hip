@@ -216,7 +216,10 @@ int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int
 // 0.93 ms against 1.14 ms - the two directions do NOT add up here: 25 MB up alone and 27 MB down alone each move
 // at ~56 GB/s, both together at ~60 GB/s in all (the same with the canvas written straight into the pinned host
 // buffer by the kernel instead of a DMA copy), so what the overlap hides is the kernels, the set-up and the
-// per-copy latencies, not half of the bytes.
+// per-copy latencies, not half of the bytes.  And pinning is not free: the FIRST call on a buffer (a new virtual range)
+// spends ~1 ms registering it and ~7 ms at its first DMA use; only later calls on the same buffers run at 0.93 ms
+// (tools/pipe_trace.py).  Hence opt-in (APAP_OPT_OVERLAP_PCIE = 1): right for a caller that streams pairs through buffers it
+// keeps, wrong for one warp into a fresh array - the default stays the plain sequence.
 // WHICH source rows a band can read is not guessed: the set-up kernel reports, per cell row, an interval that
 // contains the source row of every pixel of every cell in it (anchor row -+ the bound of the float32
 // estimate's magnitude, apap_kernels.hip fast_record), and the host takes the union over the band's cell

@@ -115,9 +115,11 @@ typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_WARP_FAST 8       /* 1 (default): K3 decides a pixel from a float32 estimate of its source coordinate
                                       and takes the exact float64 sequence only where the estimate is within its error
                                       bound of an integer (same canvas, byte for byte); 0: float64 for every pixel    */
-#define APAP_OPT_OVERLAP_PCIE 9    /* 1 (default): apap_local_warp / apap_local_stitch pin the caller's buffers for the call
-                                      and overlap the image upload, the warp (in row bands) and the canvas download on
-                                      three streams; 0: one copy up, one kernel, one copy down                         */
+#define APAP_OPT_OVERLAP_PCIE 9    /* 0 (default): apap_local_warp / apap_local_stitch make one copy up, one kernel, one copy
+                                      down.  1: they pin the caller's buffers for the call (hipHostRegister) and overlap the
+                                      image upload, the warp (in row bands) and the canvas download on three streams.  For
+                                      callers that REUSE their image / canvas buffers: the first use of a buffer pays ~8 ms of
+                                      pinning and mapping (4K pair), every later call saves ~15 %                              */
 #define APAP_OPT_PLAN_CELLS 10      /* 0 (default): the solve picks its kernel (fused small-mesh launch or K1 + K2) and its
                                       keypoint splits from THIS call's cells x batch.  c > 0: as for ONE pair of c cells,
                                       whatever the call holds - a shard of a mesh (cvx_proj_amd/dist.py) then sums every

@@ -900,23 +900,24 @@ def test_fast_warp_on_irregular_meshes_and_strong_perspective(native, seed):
 
 
 def test_overlapped_host_warp_equals_sequential(native, golden):
-    """apap_local_warp / apap_local_stitch overlap the upload, the banded warp and the download (three streams, the
-    caller's buffers pinned for the call); APAP_OPT_OVERLAP_PCIE = 0 is one copy up, one kernel, one copy down.
+    """With APAP_OPT_OVERLAP_PCIE = 1 apap_local_warp / apap_local_stitch overlap the upload, the banded warp and the
+    download (three streams, the caller's buffers pinned for the call); the default is one copy up, one kernel, one copy down.
     Same canvas and same write-back of the inverses, byte for byte - on a BASELINE pair (bands start as soon as the
     source rows they can read have landed), on a pair rotated by 90 degrees (every band needs rows from the far end
     of the source), and on a mesh with edges out of order (no source-row intervals: the bands wait for the whole image)."""
     import hashlib
-    seq = native.Context(overlap_pcie=0)
+    seq = None                                   # the default: sequential
+    ovl = native.Context(overlap_pcie=1)
     try:
         g = golden("c3_ref")
         p = config_pair("C3")
-        w1, h1 = native.local_warp(p.img, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+        w1, h1 = native.local_warp(p.img, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=ovl)
         assert hashlib.sha256(w1.tobytes()).digest() == g["warped_sha256"].tobytes()
-        w0, h0 = native.local_warp(p.img, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=seq)
+        w0, h0 = native.local_warp(p.img, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
         assert np.array_equal(w0, w1) and np.array_equal(h0, h1)
         center = np.random.default_rng(4).integers(0, 256, p.shape, dtype=np.uint8)
-        s1, _ = native.local_stitch(p.img, center, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
-        s0, _ = native.local_stitch(p.img, center, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=seq)
+        s1, _ = native.local_stitch(p.img, center, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=ovl)
+        s0, _ = native.local_stitch(p.img, center, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
         assert np.array_equal(s0, s1)
         # rotation by 90 degrees: canvas row y reads source column y - the first band needs the last source rows
         rng = np.random.default_rng(8)
@@ -925,19 +926,19 @@ def test_overlapped_host_warp_equals_sequential(native, golden):
         Hrot = np.tile(np.array([[0, -1, 1499.5], [1, 0, 0.25], [0, 0, 1]], np.float32), (m, m, 1, 1))
         Hrot += rng.normal(0, 1e-4, Hrot.shape).astype(np.float32) * np.array([[1, 1, 100], [1, 1, 100], [1e-4, 1e-4, 0]], np.float32)
         mesh_w, mesh_h = np.linspace(0, fw, m + 1), np.linspace(0, fh, m + 1)
-        r1, _ = native.local_warp(img, Hrot, mesh_w, mesh_h, fw, fh, 0, 0)
-        r0, _ = native.local_warp(img, Hrot, mesh_w, mesh_h, fw, fh, 0, 0, ctx=seq)
+        r1, _ = native.local_warp(img, Hrot, mesh_w, mesh_h, fw, fh, 0, 0, ctx=ovl)
+        r0, _ = native.local_warp(img, Hrot, mesh_w, mesh_h, fw, fh, 0, 0)
         assert np.array_equal(r0, r1) and r1.any()
         hinv = np.linalg.inv(Hrot.astype(np.float64)).astype(np.float32)
         assert np.array_equal(r1[::97], O.local_warp_fast(img, hinv, (mesh_w, mesh_h), (fw, fh), (0, 0))[::97])
         # edges out of order
         bad_h = mesh_h.copy()
         bad_h[[10, 11]] = bad_h[[11, 10]]
-        b1, _ = native.local_warp(img, Hrot, mesh_w, bad_h, fw, fh, 0, 0)
-        b0, _ = native.local_warp(img, Hrot, mesh_w, bad_h, fw, fh, 0, 0, ctx=seq)
+        b1, _ = native.local_warp(img, Hrot, mesh_w, bad_h, fw, fh, 0, 0, ctx=ovl)
+        b0, _ = native.local_warp(img, Hrot, mesh_w, bad_h, fw, fh, 0, 0)
         assert np.array_equal(b0, b1)
     finally:
-        seq.close()
+        ovl.close()
 
 
 def test_source_with_a_side_of_2_to_the_24_takes_the_flat_order_kernel(native):
