@@ -2184,11 +2184,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     float dxf[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-#ifdef APAP_K3_ABL_ARITHCOL   // experiment (wrong pixels at cell edges): cell column without waiting for the table
-        col[k] = (unsigned)(((unsigned long long)(unsigned)min(j0 + k, final_w - 1) * (unsigned)mesh_cols) / (unsigned)final_w);
-#else
         col[k] = cev[k] & 0xffffu;
-#endif
         dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
     // row entries: wave-uniform, scalar loads
@@ -2197,11 +2193,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const uint2 e = frow[(unsigned)min(y_first + t, y_end - 1)];
-#ifdef APAP_K3_ABL_ARITHCOL
-        rr[t] = (unsigned)(((unsigned long long)(unsigned)min(y_first + t, y_end - 1) * (unsigned)mesh_rows) / (unsigned)final_h);
-#else
         rr[t] = __builtin_amdgcn_readfirstlane(e.x);
-#endif
         dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.y));
     }
     unsigned off[kRows][4];
