@@ -34,9 +34,11 @@ def get_vertice(size, mesh_size, offsets):
     col_x = np.linspace(0, width, mesh_size) + width / (mesh_size * 2)
     row_y = np.linspace(0, height, mesh_size) + height / (mesh_size * 2)
     out = np.empty((mesh_size, mesh_size, 2), dtype=np.float64)
-    out[..., 0] = col_x[None, :]
-    out[..., 1] = row_y[:, None]
-    out -= np.array(offsets)
+    # (x - offset) per column / row, then broadcast: the same float64 subtraction the reference applies to the
+    # whole (m, m, 2) array, one pass over it instead of three
+    off = np.array(offsets)
+    out[..., 0] = (col_x - off[0])[None, :]
+    out[..., 1] = (row_y - off[1])[:, None]
     return out
 
 
