@@ -125,3 +125,36 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "apap_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_abi_generation_is_checked_on_load(native, monkeypatch):
+    """A build of another ABI generation keeps the symbol names but not the argument lists (generation 2 put the
+    context first): the binding must refuse it instead of calling into it."""
+    assert native.lib().apap_abi_version() == native.ABI_VERSION
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "ABI_VERSION", native.ABI_VERSION + 1)
+    with pytest.raises(native.ApapError, match="ABI generation"):
+        native.lib()
+    monkeypatch.undo()
+    assert native.lib().apap_abi_version() == native.ABI_VERSION
+
+
+def test_plan_cells_option_fixes_the_launch_plan(native):
+    """APAP_OPT_PLAN_CELLS: kernel choice and keypoint splits as for ONE pair of that many cells, whatever the call
+    holds (a shard of a mesh then sums like the whole mesh).  Visible without a GPU in the workspace size: a slab of 30
+    doubles per cell and keypoint split."""
+    lib = native.lib()
+    slab = lambda cells: 30 * ((cells + 63) // 64 * 64) * 8      # noqa: E731
+    ctx = native.Context(variant=native.VARIANT_MFMA)
+    whole, shard = 160000, 20000                                 # C4 and one of its 8 row blocks, 5000 keypoints
+    assert lib.apap_solve_workspace_bytes(native._h(ctx), 5000, whole) == slab(whole)            # 10 000 waves: one split
+    by_itself = lib.apap_solve_workspace_bytes(native._h(ctx), 5000, shard)
+    assert by_itself == 4 * slab(shard)                                                          # 313 tiles alone: four keypoint splits to fill the chip
+    ctx.set("plan_cells", whole)
+    assert lib.apap_solve_workspace_bytes(native._h(ctx), 5000, shard) == slab(shard)            # as the whole mesh: one split
+    assert lib.apap_solve_batch_workspace_bytes(native._h(ctx), 5000, shard, 3) == 3 * slab(shard)
+    ctx.set("plan_cells", 0)
+    assert lib.apap_solve_workspace_bytes(native._h(ctx), 5000, shard) == by_itself
+    with pytest.raises(native.ApapError):
+        ctx.set("plan_cells", -1)
+    ctx.close()
