@@ -661,6 +661,7 @@ def main():
         tc_solve = timed(cs.solve, a.steps)
         tc_warp = timed(cs.warp, a.steps)
         tc_bands = timed(lambda: cs.warp(gather=False), a.steps)      # the canvas left distributed: no collective
+        tc_step = timed(cs.step, a.steps)                             # solve + H gather in flight + own band + wait
         assert int(cs.status.cpu()[0]) == 0
         ctx.set("profile", 1)
         for _ in range(min(a.steps, 10)):
@@ -684,7 +685,12 @@ def main():
             "warp_bands_only": {"value": cp.final_w * cp.final_h * a.steps / tc_bands / 1e6, "unit": "Mpix/s",
                                 "ms_per_step": tc_bands / a.steps * 1e3,
                                 "note": "row bands left where they are computed (no collective): the part of the warp that "
-                                        "shards; SURVEY.md 8e expects the gathered form to be transfer-dominated"},
+                                        "shards; SURVEY.md 8e expects the gathered form to be transfer-dominated.  Bands are aligned to the "
+                                        "mesh rows a rank solved: its set-up kernel inverts 1 / world of the cells"},
+            "pipelined_step": {"ms_per_step": tc_step / a.steps * 1e3,
+                               "note": "ShardedSolver.step(): each rank solves its mesh rows, starts the all-gather of the H grid, "
+                                       "warps ITS band (the canvas rows of its own mesh rows, from its own rows of the grid) "
+                                       "while the gather runs, then waits: solve + warp_bands_only with the collective hidden"},
             "table_broadcast_ms": t_bcast * 1e3, "first_warp_incl_image_broadcast_ms": t_first_warp * 1e3,
             "collectives_per_step": "solve: the H grid (36 B per cell) in 2 all-gathers, the first beside the second half's "
                                     "kernels; warp: 1 all-gather of the canvas bands" if world > 1 else "none",

@@ -165,6 +165,7 @@ class ShardedSolver:
         self.cells = self.cells_total
         self.my_cells = (b - a) * self.cols          # what this rank's kernels work on
         self._inputs_sent = False
+        self._pending = []
         self._solve_kw = dict(self._kw)
         if solve_fn is hip_solve:                   # the engine's scratch: sized once for the larger launch
             nb = max([max(_native.lib().apap_solve_workspace_bytes(_native._h(ctx), self.n, v.shape[0]), 256) if v.shape[0] else 256
@@ -191,33 +192,66 @@ class ShardedSolver:
             mine[:vert.shape[0]].copy_(res)
         return mine
 
-    def solve(self, stream=None):
+    def solve(self, stream=None, wait=True):
+        """Solve this rank's rows and all-gather the H grid.  The rank's own rows are in ``self.H`` as soon as
+        their kernels have run (what its own warp band needs); with ``wait=False`` the all-gathers are left in
+        flight - ``finish()`` waits for them and puts the other ranks' rows in place."""
         d = self.dist
         if not self._inputs_sent:
             self.broadcast_inputs()
+        self.finish()
         if d is None or self.world == 1:
             mine = self._solve_piece(0)
             self.H.copy_(mine[:self.cells_total])
             return self.H
-        pending = []
         for k in range(2 if self.overlap else 1):
             mine = self._solve_piece(k)
-            # async: the collective is ordered after this piece's kernels and runs beside the next piece's
-            pending.append(d.all_gather_into_tensor(self._gather[k].view(-1, 9), mine, async_op=True))
-        for k, w in enumerate(pending):
+            pa, pb = self._pieces[k][self.rank]
+            if pb > pa:
+                self.H[pa * self.cols:pb * self.cols].copy_(mine[:(pb - pa) * self.cols])
+            # async: the collective is ordered after this piece's kernels and runs beside whatever comes next
+            self._pending.append((k, d.all_gather_into_tensor(self._gather[k].view(-1, 9), mine, async_op=True)))
+        if wait:
+            self.finish()
+        return self.H
+
+    def finish(self):
+        """Wait for the all-gathers ``solve(wait=False)`` left in flight; afterwards ``self.H`` is the whole grid."""
+        for k, w in self._pending:
             w.wait()
             g = self._gather[k].view(-1, 9)
             if self._src[k].numel() != g.shape[0]:      # uneven shards: drop the padding
                 g = g.index_select(0, self._src[k])
             self.H.index_copy_(0, self._dst[k], g)
+        self._pending = []
         return self.H
 
+    def step(self, gather_canvas=False):
+        """One pipelined step of the pair: solve this rank's rows, start the all-gather of the H grid, warp this
+        rank's band FROM ITS OWN ROWS while the gather runs, then wait for the gather.  Returns ``(H, band or canvas)``."""
+        self.solve(wait=False)
+        band = self.warp(gather=gather_canvas)
+        return self.finish(), band
+
     def _warp_setup(self):
-        """Once per pair: the source image reaches every rank by a broadcast from rank 0
-        (25 MB at 4K, 100 MB at 8K - the transfer SURVEY.md 8e warns dominates a single
-        warp); canvas rows are dealt in contiguous near-equal bands."""
+        """Once per pair: the source image reaches every rank by a broadcast from rank 0 (25 MB at 4K, 100 MB at 8K
+        - the transfer SURVEY.md 8e warns dominates a single warp).  Canvas rows are dealt in bands ALIGNED TO THE
+        RANK'S OWN MESH ROWS: band r = the canvas rows whose cell row rank r solved, so a rank warps
+        from its own rows of the H grid - no wait for the all-gather - and its set-up kernel inverts 1 / world of
+        the cells instead of all of them.  The engine sees the rank's rows as a mesh of their own: edges
+        ``mesh_h[a : b + 1]`` with the last one opened to +inf (canvas rows outside the band must still look up
+        SOME cell; they are not warped).  Needs increasing row edges starting at or below 0; any other mesh keeps
+        near-equal bands warped from the whole gathered grid."""
         p, d = self.pair, self.dist
-        self.bands = row_partition(p.final_h, self.world)
+        edges = np.asarray(p.mesh[1], dtype=np.float64)
+        self._aligned = (self.world > 1 and len(edges) == self.rows + 1 and bool(np.all(np.diff(edges) > 0)) and edges[0] <= 0.0
+                         and bool(np.isfinite(edges).all()))
+        if self._aligned:
+            first = lambda k: int(min(max(np.ceil(edges[k]), 0.0), p.final_h)) if k < self.rows else p.final_h   # noqa: E731
+            self.bands = [(first(ra), first(rb)) if rb > ra else (first(ra), first(ra)) for ra, rb in self.parts]
+            self.bands[0] = (0, self.bands[0][1])
+        else:
+            self.bands = row_partition(p.final_h, self.world)
         self.max_band = max(b - a for a, b in self.bands)
         if self.rank == 0 and p.img is not None:
             self.img = torch.from_numpy(np.ascontiguousarray(p.img)).to(self.dev)
@@ -226,24 +260,32 @@ class ShardedSolver:
         if d is not None and self.world > 1:
             d.broadcast(self.img, src=0)
         self.mesh_w = torch.from_numpy(np.ascontiguousarray(p.mesh[0])).to(self.dev)
-        self.mesh_h = torch.from_numpy(np.ascontiguousarray(p.mesh[1])).to(self.dev)
+        ra, rb = self.my_rows
+        if self._aligned and rb > ra:
+            own = edges[ra:rb + 1].copy()
+            own[-1] = np.inf
+            self.mesh_h = torch.from_numpy(own).to(self.dev)
+            self._warp_shape = (rb - ra, self.cols)
+        else:
+            self.mesh_h = torch.from_numpy(np.ascontiguousarray(edges)).to(self.dev)
+            self._warp_shape = (self.rows, self.cols)
         if self.warp_fn is hip_warp_rows:       # the engine's scratch and status word: once
-            nb = _native.lib().apap_warp_workspace_bytes(self.rows, self.cols, p.final_w, p.final_h)
+            nb = _native.lib().apap_warp_workspace_bytes(self._warp_shape[0], self._warp_shape[1], p.final_w, p.final_h)
             self._warp_kw = dict(self._kw, work=torch.empty(nb, dtype=torch.uint8, device=self.dev), status=self.status)
         else:
             self._warp_kw = dict(self._kw)
-        self._band = torch.zeros((self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
-        self._bands = torch.zeros((self.world, self.max_band, p.final_w, 3), dtype=torch.uint8, device=self.dev)
-        dst = np.concatenate([np.arange(ra, rb) for ra, rb in self.bands])
-        src = np.concatenate([r * self.max_band + np.arange(rb - ra) for r, (ra, rb) in enumerate(self.bands)])
+        self._band = torch.zeros((max(self.max_band, 1), p.final_w, 3), dtype=torch.uint8, device=self.dev)
+        self._bands = torch.zeros((self.world, max(self.max_band, 1), p.final_w, 3), dtype=torch.uint8, device=self.dev)
+        dst = np.concatenate([np.arange(ba, bb) for ba, bb in self.bands])
+        src = np.concatenate([r * max(self.max_band, 1) + np.arange(bb - ba) for r, (ba, bb) in enumerate(self.bands)])
         self._band_dst = torch.from_numpy(dst.astype(np.int64)).to(self.dev)
         self._band_src = torch.from_numpy(src.astype(np.int64)).to(self.dev)
         self.out = torch.zeros((p.final_h, p.final_w, 3), dtype=torch.uint8, device=self.dev)
 
     def warp(self, stream=None, gather=True):
-        """Backward warp of the pair with canvas rows sharded over the ranks: every rank
-        warps its band from the full H grid (present on every rank after ``solve``), one
-        all-gather assembles the canvas on every rank.  Returns ``self.out``.
+        """Backward warp of the pair with canvas rows sharded over the ranks: every rank warps its band - from its
+        own rows of the H grid when the bands are aligned to the mesh rows (``_warp_setup``), from the whole
+        gathered grid otherwise; one all-gather assembles the canvas on every rank.  Returns ``self.out``.
 
         ``gather=False`` stops after the band: the canvas stays distributed (rank r holds rows
         ``self.bands[r]`` in ``self._band``) - what a pipeline that writes or consumes the bands in
@@ -253,15 +295,22 @@ class ShardedSolver:
         p, d = self.pair, self.dist
         a, b = self.bands[self.rank]
         single = d is None or self.world == 1
-        st = self.warp_fn(self.img, self.H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
-                          self.out if single else self._band, (self.rows, self.cols), **self._warp_kw)   # one rank: straight into the canvas
-        if st is not None:
-            self.status = st
+        if self._aligned:
+            ra, rb = self.my_rows
+            H = self.H[ra * self.cols:rb * self.cols]           # this rank's own rows: valid before the gather ends
+        else:
+            self.finish()
+            H = self.H
+        if b > a or single:
+            st = self.warp_fn(self.img, H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
+                              self.out if single else self._band, self._warp_shape, **self._warp_kw)   # one rank: straight into the canvas
+            if st is not None:
+                self.status = st
         if single:
             return self.out
         if not gather:
             return self._band[:b - a]
-        if all(rb - ra == b - a for ra, rb in self.bands):
+        if all(bb - ba == b - a for ba, bb in self.bands):
             d.all_gather_into_tensor(self.out, self._band[:b - a])
             return self.out
         d.all_gather_into_tensor(self._bands.view(-1, p.final_w, 3), self._band)

@@ -39,6 +39,9 @@ def main():
     band = s.warp(gather=False).cpu().numpy()             # the canvas left distributed: this rank's rows only
     lo, hi = s.bands[rank]
     assert np.array_equal(band, canvas[lo:hi])
+    assert s._aligned                                     # bands = the canvas rows of the mesh rows this rank solved
+    H_step, band_step = s.step()                          # solve -> H gather in flight -> warp of the own band -> wait
+    assert np.array_equal(H_step.cpu().numpy(), H) and np.array_equal(band_step.cpu().numpy(), canvas[lo:hi])
     pairs = [config_pair("C1", with_image=False, seed_offset=k) for k in range(5)]
     grids = solve_pairs(pairs, dev, dist)
     gathered = [None] * world

@@ -84,6 +84,13 @@ def worker(rank, world, port, rows, q):
         assert s.bands[0][0] == 0 and s.bands[-1][1] == p.final_h
         lo, hi = s.bands[rank]
         assert np.array_equal(s.warp(gather=False).numpy(), canvas[lo:hi])   # the canvas left distributed: own rows only
+        # bands follow the mesh rows each rank solved: the warp reads the rank's OWN rows of the grid
+        assert s._aligned and [b for b in s.bands if b[1] > b[0]][0][0] == 0
+        H_step, band = s.step()                                  # solve, gather in flight, warp own band, wait
+        assert np.array_equal(H_step.numpy(), H) and np.array_equal(band.numpy(), canvas[lo:hi])
+        s.solve(wait=False)
+        assert len(s._pending) > 0
+        assert np.array_equal(s.finish().numpy(), H) and s._pending == []
         pairs = [synth_pair(320, 240, 60, 4, seed=100 + k) for k in range(5)]
         grids = solve_pairs(pairs, torch.device("cpu"), dist, solve_fn=oracle_solve)
         q.put((rank, s.parts, H, grids, canvas))
