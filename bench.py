@@ -659,6 +659,14 @@ def main():
             cs.solve()
             cs.warp()
         tc_solve = timed(cs.solve, a.steps)
+        tc_other = None
+        if world > 1:           # the other form of the solve (one launch + one gather / two launches, first gather overlapped)
+            co = ShardedSolver(cp, dev, dist, ctx=ctx, overlap=not cs.overlap)
+            co.broadcast_inputs()
+            for _ in range(a.warmup + 3):
+                co.solve()
+            tc_other = timed(co.solve, a.steps)
+            del co
         tc_warp = timed(cs.warp, a.steps)
         tc_bands = timed(lambda: cs.warp(gather=False), a.steps)      # the canvas left distributed: no collective
         tc_step = timed(cs.step, a.steps)                             # solve + H gather in flight + own band + wait
@@ -695,6 +703,10 @@ def main():
             "collectives_per_step": "solve: the H grid (36 B per cell) in 2 all-gathers, the first beside the second half's "
                                     "kernels; warp: 1 all-gather of the canvas bands" if world > 1 else "none",
             "collectives_overlapped": bool(cs.overlap),
+            "solve_other_form_ms_per_step": None if tc_other is None else tc_other / a.steps * 1e3,
+            "solve_forms_note": "solve_ms_per_step is ShardedSolver's default for this world size (two launches per rank with the "
+                                "first all-gather beside the second for 2-4 ranks, one launch + one gather above: a model, "
+                                "cvx_proj_amd/dist.py); solve_other_form_ms_per_step is the other form on the same ranks",
             "rank0_cells": cs.my_cells, "kernels_ms": ckern,
             "roofline": None if c_ach is None else {
                 "kernel": "k_assemble (rank 0's shard)", "bound": "mfma", "achieved": c_ach, "peak": PEAK_FP64_TFLOPS,

@@ -104,10 +104,16 @@ class ShardedSolver:
     grid; afterwards ``self.H`` holds the full grid on every rank (what a following sharded
     warp needs for its own rows, and what rank 0 writes).
 
-    The rank's rows are solved in TWO launches and the first half's all-gather runs while the second half is
-    being computed (``overlap=True``): at 8 ranks a C4 shard is ~170 us of kernels, a latency-bound collective of
-    20-50 us would otherwise be 10-25 % of the step.  Every buffer of the step (shard grids, gather buffers,
-    scratch, status) is allocated here, once.
+    With ``overlap=True`` the rank's rows are solved in TWO launches and the first half's all-gather runs while
+    the second half is being computed.  What that buys depends on what bounds the collective: the second gather is
+    exposed either way, so a latency-bound gather gains nothing and the split costs its launch overhead - measured on
+    one GPU playing a rank of C4 (``tools/shard_solve_cost.py``): +11 us at 2 ranks (715 -> 726 us), +15 at 4,
+    +24 at 8 (189 -> 213 us).  The H grid is 36 B per cell: at 2 ranks a rank receives 2.9 MB over one xGMI link
+    (bandwidth-bound, ~60 us: hiding half of it pays), at 8 ranks 720 KB over each of 7 links (~15 us of wire time
+    under ~20 us of latency: it does not).  ``overlap="auto"`` (default) therefore splits for world sizes up to 4.
+    No multi-GPU hardware was available to this builder: the rule is a model, and ``bench.py`` times both forms on
+    whatever it runs on.  What hides the collective at any size is ``step()``: the gather runs beside the rank's own
+    warp band.  Every buffer of the step (shard grids, gather buffers, scratch, status) is allocated here, once.
 
     ``same_bits=True`` makes the shards sum every cell's keypoints in the order the whole mesh would on one GPU
     (``APAP_OPT_PLAN_CELLS``): the gathered grid then equals the single-GPU grid bit for bit for any number of
@@ -116,7 +122,7 @@ class ShardedSolver:
     a few thousand may round the other way; the 1e-4 px parity bar is six orders of magnitude above that).
     """
 
-    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows, ctx=None, overlap=True,
+    def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows, ctx=None, overlap="auto",
                  same_bits=False):
         self.pair, self.dev, self.dist, self.solve_fn, self.warp_fn = pair, dev, dist, solve_fn, warp_fn
         self.rank = dist.get_rank() if dist is not None else 0
@@ -130,7 +136,7 @@ class ShardedSolver:
         # a _native.Context (options, profiling) handed to the default HIP compute functions
         self._ctx = ctx
         self._kw = {"ctx": ctx} if ctx is not None else {}
-        self.overlap = bool(overlap) and self.world > 1
+        self.overlap = (2 <= self.world <= 4) if overlap == "auto" else (bool(overlap) and self.world > 1)
         self.n = len(pair.src)
         self.parts = row_partition(self.rows, self.world)
         self.max_rows = max(b - a for a, b in self.parts)

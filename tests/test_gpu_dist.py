@@ -81,6 +81,6 @@ def test_bench_self_launch_reports_pairs_and_cells(native):
     assert c["rank0_cells"] == 50 * 100                               # half of the 100 x 100 mesh
     assert 0.0 < c["roofline"]["frac"] < 1.0 and c["value"] > 0 and c["warp"]["value"] > 0
     assert c["warp_bands_only"]["value"] >= c["warp"]["value"] * 0.9      # the all-gather can only cost
-    assert c["collectives_overlapped"] is True
+    assert c["collectives_overlapped"] is True and c["solve_other_form_ms_per_step"] > 0 and c["pipelined_step"]["ms_per_step"] > 0
     one = d["roofline"]["frac"]
     assert c["roofline"]["frac"] < 2.5 * one                          # not inflated by the world size
