@@ -48,6 +48,7 @@ import time
 import numpy as np
 import torch
 
+T0 = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -188,18 +189,26 @@ class Resident:
 
 class PairBatch:
     """BASELINE config 5: independent pairs sharing one mesh shape, this rank's share solved in ONE batched
-    launch (blockIdx.z = pair); keypoint tables, de-normalisation blocks, vertices and the H grids resident."""
+    launch (blockIdx.z = pair) and warped in ONE batched set of launches (one set-up launch over every pair's cells,
+    one gather launch over every canvas); keypoint tables, de-normalisation blocks, vertices, the H grids, the source
+    images and the canvases resident."""
 
-    def __init__(self, cfg, indices, dev, ctx=None):
+    def __init__(self, cfg, indices, dev, ctx=None, with_images=True):
         self.ctx = N._h(ctx)
         self.batch = len(indices)
-        tabs, dens = [], []
+        tabs, dens, imgs = [], [], []
         pair = None
         for k in indices:
-            pair = config_pair(cfg, with_image=False, seed_offset=k)
+            pair = config_pair(cfg, with_image=with_images, seed_offset=k)
             q = N.host_prepare(pair.src, pair.dst)
             tabs.append(N.host_build_table(pair.src, q["cf1"], q["cf2"]))
             dens.append(N.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"]))
+            if with_images:
+                imgs.append(torch.from_numpy(pair.img).to(dev))        # 25 MB per 4K pair: upload at once, keep the host small
+                if k != indices[0]:
+                    pair.img = None
+                else:
+                    self.first = pair
         self.pair = pair
         self.n = len(pair.src)
         self.rows, self.cols = pair.vertices.shape[:2]
@@ -210,12 +219,43 @@ class PairBatch:
         self.H = torch.zeros((self.batch * self.cells, 9), dtype=torch.float32, device=dev)
         self.work_bytes = max(N.lib().apap_solve_batch_workspace_bytes(self.ctx, self.n, self.cells, self.batch), 256)
         self.work = torch.empty(self.work_bytes, dtype=torch.uint8, device=dev)
+        if with_images:
+            self.imgs = torch.stack(imgs)
+            del imgs
+            self.mesh_w, self.mesh_h = t(pair.mesh[0]), t(pair.mesh[1])
+            self.out = torch.zeros((self.batch, pair.final_h, pair.final_w, 3), dtype=torch.uint8, device=dev)
+            self.wwork_bytes = N.lib().apap_warp_batch_workspace_bytes(self.rows, self.cols, pair.final_w, pair.final_h, self.batch)
+            self.wwork = torch.empty(self.wwork_bytes, dtype=torch.uint8, device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def solve(self, stream):
         p = self.pair
         N.check(N.lib().apap_solve_batch_device(self.ctx, self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, self.cells,
                                                 p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(), self.batch,
                                                 self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
+
+    def warp(self, stream, phases=N.WARP_ALL):
+        p = self.pair
+        N.check(N.lib().apap_warp_batch_device(self.ctx, self.imgs.data_ptr(), self.imgs[0].numel(), p.shape[0], p.shape[1], None, 0, 0, 0,
+                                               self.H.data_ptr(), self.rows, self.cols, self.mesh_w.data_ptr(), p.mesh.shape[1],
+                                               self.mesh_h.data_ptr(), p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y, 0,
+                                               p.final_h, self.out.data_ptr(), self.out[0].numel(), None, self.batch, phases,
+                                               self.wwork.data_ptr(), self.wwork_bytes, self.status.data_ptr(), ctypes.c_void_p(stream)))
+
+    def check_against_single_launches(self, stream, which=(0,)):
+        """The batched canvases of pairs `which` (positions in this batch) against one apap_warp_device launch each."""
+        p = self.pair
+        wb = N.lib().apap_warp_workspace_bytes(self.rows, self.cols, p.final_w, p.final_h)
+        work = torch.empty(wb, dtype=torch.uint8, device=self.out.device)
+        one = torch.zeros_like(self.out[0])
+        for i in which:
+            N.check(N.lib().apap_warp_device(self.ctx, self.imgs[i].data_ptr(), p.shape[0], p.shape[1],
+                                             self.H[i * self.cells:].data_ptr(), self.rows, self.cols, self.mesh_w.data_ptr(),
+                                             p.mesh.shape[1], self.mesh_h.data_ptr(), p.mesh.shape[1], p.final_w, p.final_h, p.off_x,
+                                             p.off_y, one.data_ptr(), None, work.data_ptr(), wb, self.status.data_ptr(),
+                                             ctypes.c_void_p(stream)))
+            torch.cuda.synchronize()
+            assert torch.equal(one, self.out[i]) and bool(one.any()), f"batched canvas of pair {i} differs from its own launch"
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -493,12 +533,30 @@ def main():
     if world > 1:
         import torch.distributed as dist
         backend = os.environ.get("APAP_BENCH_BACKEND", "nccl")      # nccl = RCCL on ROCm
+        # first contact with RCCL must not hang silently: a short collective timeout (the default is 10 minutes, the
+        # driver's limit for the whole run is not much more) and a phase marker on stderr before every phase that
+        # holds a collective, so that a run killed at its limit has said where it was
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("APAP_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     else:
         dist = None
+
+    def phase(name):
+        if rank == 0:
+            print(json.dumps({"bench_phase": name, "n_gpus": world, "backend": backend, "t": round(time.time() - T0, 2)}),
+                  file=sys.stderr, flush=True)
+    phase("process group up")
+    if dist is not None:
+        # one tiny collective first: if the transport is broken this fails within the timeout, before any long phase
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert int(probe.cpu()[0]) == world, "all_reduce across the ranks returned a wrong sum"
+        phase("first collective done")
 
     ctx = N.Context(variant=VARIANTS[a.variant])        # options + profiling live in a context, not in the process
     if a.want_waves:
@@ -546,6 +604,7 @@ def main():
             torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ pairs: the headline
+    phase("pair_per_rank (no data-path collective; barriers only)")
     pair = config_pair(a.config, seed_offset=rank * a.batch)
     extras = [config_pair(a.config, with_image=False, seed_offset=rank * a.batch + k) for k in range(1, a.batch)]
     res = Resident(pair, dev, a.batch, extras, ctx=ctx)
@@ -649,6 +708,7 @@ def main():
     # ------------------------------------------------------------------ pairs as BASELINE config 5 states them
     c5_obj = None
     if not a.no_c5:
+        phase("pairs (config 5; no data-path collective)")
         total_pairs = a.c5_pairs
         mine = list(range(rank, total_pairs, world))          # dealt round-robin: 64 / N per rank
         pb = PairBatch("C5", mine, dev, ctx=ctx) if mine else None
@@ -657,17 +717,43 @@ def main():
             for _ in range(a.warmup):
                 pb.solve(stream)
         t_c5 = timed((lambda: pb.solve(stream)) if pb is not None else (lambda: None), a.steps)
+        # the warp half of config 5: this rank's pairs in one set-up launch + one gather launch (grid.z = pair)
+        if pb is not None:
+            for _ in range(max(a.warmup, 2)):
+                pb.warp(stream)
+            pb.check_against_single_launches(stream, which=sorted({0, pb.batch - 1}))
+        w_steps = max(4, a.steps // 4)          # a step is 64 / N pairs: ~1 ms
+        t_c5w = timed((lambda: pb.warp(stream)) if pb is not None else (lambda: None), w_steps)
+        # ... and with the geometry tables kept from the first call (they depend on the edges and the canvas only)
+        t_c5g = timed((lambda: pb.warp(stream, N.WARP_CELLS | N.WARP_GATHER)) if pb is not None else (lambda: None), w_steps)
+        if pb is not None:
+            assert int(pb.status.cpu()[0]) == 0, "device status word set by the batched warp"
         cells_c5 = CONFIGS["C5"][3] ** 2
+        c5_pixels = (pb.pair.final_w * pb.pair.final_h) if pb is not None else 0
+        if dist is not None:
+            tt = torch.tensor([float(c5_pixels)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            c5_pixels = int(tt.cpu()[0])
         c5_obj = {"workload": f"C5: {total_pairs} independent 3840x2160 pairs, 2000 correspondences, 100x100 mesh each; "
                               f"{len(mine)} per rank in ONE batched launch", "world_size": world, "scaling": "strong",
                   "value": total_pairs * cells_c5 * a.steps / t_c5, "unit": "homographies/s",
                   "solve_ms_per_step": t_c5 / a.steps * 1e3, "pairs_per_s": total_pairs * a.steps / t_c5,
-                  "pairs_per_rank": len(mine), "collectives_per_step": "none (independent pairs)"}
+                  "pairs_per_rank": len(mine), "collectives_per_step": "none (independent pairs)",
+                  "warp": {"value": total_pairs * c5_pixels * w_steps / t_c5w / 1e6, "unit": "Mpix/s",
+                           "ms_per_step": t_c5w / w_steps * 1e3, "us_per_pair": t_c5w / w_steps / max(len(mine), 1) * 1e6,
+                           "steps": w_steps,
+                           "geometry_kept_us_per_pair": t_c5g / w_steps / max(len(mine), 1) * 1e6,
+                           "note": "apap_warp_batch_device: one set-up launch over every pair's cells and one gather launch over "
+                                   "every canvas of the rank's pairs (grid.z = pair), source images and canvases resident; the "
+                                   "canvases of the first and last pair are checked against one apap_warp_device launch each; "
+                                   "us_per_pair is per pair of ONE rank's share; geometry_kept = APAP_WARP_CELLS | APAP_WARP_GATHER on "
+                                   "a workspace whose canvas row / column tables are kept from an earlier call"}}
         del pb
 
     # ------------------------------------------------------------------ cells: one pair sharded
     cells_obj = None
     if not a.no_cells:
+        phase("cells (config 4: table broadcast, H all-gather, canvas all-gather)")
         from cvx_proj_amd.dist import ShardedSolver
         cp = config_pair(a.cells_config, with_image=(rank == 0))
         cs = ShardedSolver(cp, dev, dist, ctx=ctx)
@@ -863,4 +949,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:      # noqa: BLE001  (leave evidence and a non-zero exit code; never re-exec a process that touched the GPU)
+        import traceback
+        traceback.print_exc()
+        print(json.dumps({"bench_failed": repr(e)[:300], "rank": os.environ.get("RANK", "0")}), file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os._exit(1)                 # a hung collective's threads must not keep the process alive

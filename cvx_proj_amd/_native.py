@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("APAP_HIP_LIB") or os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
-ABI_VERSION = 3          # APAP_ABI_VERSION of include/apap_hip.h
+ABI_VERSION = 4          # APAP_ABI_VERSION of include/apap_hip.h
 # kernel slots of apap_ctx_profile_read (include/apap_hip.h)
 PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply", "ransac")
 PROF_SLOTS = len(PROF_NAMES)
@@ -110,6 +110,10 @@ SIGNATURES = {
     "apap_warp_rows_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_size_t, _vp,
                                         _vp]),
+    "apap_warp_batch_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "apap_warp_batch_device": (C.c_int, [_vp, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_longlong, C.c_int, C.c_int, _vp, C.c_int,
+                                         C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         _vp, C.c_longlong, _vp, C.c_int, C.c_int, _vp, C.c_size_t, _vp, _vp]),
     "apap_stitch_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int,
                                      _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
     "apap_warp_coords_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int,
@@ -408,6 +412,7 @@ def equalize_hist(img, device=-1, ctx=None):
     return out
 
 
+WARP_GEOMETRY, WARP_CELLS, WARP_GATHER, WARP_ALL = 1, 2, 4, 7      # phases of apap_warp_batch_device
 RANSAC_ITERATIONS = 2048                 # include/apap_hip.h
 RANSAC_SEED = 0x5EEDC0DE5EEDC0DE
 

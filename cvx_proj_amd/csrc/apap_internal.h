@@ -81,12 +81,13 @@ struct SolvePlan {
 SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, int plan_cells = 0);
 
 // ---- the warp in two phases on one workspace (the host-buffer entry points overlap PCIe with it) ----
-constexpr int kWarpSetup = 1;      // cell inverses, fast records, lookup tables (and, if asked, source-row intervals)
-constexpr int kWarpRows = 2;       // the gather kernel over canvas rows [row_begin, row_begin + row_count)
+constexpr int kWarpSetup = APAP_WARP_GEOMETRY | APAP_WARP_CELLS;   // lookup tables + cell inverses and fast records (and, if asked, source-row intervals)
+constexpr int kWarpRows = APAP_WARP_GATHER;   // the gather kernel over canvas rows [row_begin, row_begin + row_count)
 // apap_warp_rows_device / apap_stitch_device with a choice of phases.  With `d_src_rows` non-null the set-up also
 // fills, per cell row, the interval of source rows its pixels can read (device ints [rows][2], then one flag word:
 // bit 0 = irregular mesh, intervals void); the caller pre-sets the lower bounds to a large and the upper bounds to a
-// small value.  *d_src_rows is set to the device address, or to NULL when this mesh has no such table.
+// small value.  *d_src_rows is set to the device address, or to NULL when this mesh has no such table; phase 0 only
+// reports that address and launches nothing.
 int warp_phase(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h, int center_w,
                const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out_band, float *d_Hinv_out, void *d_work,

@@ -1644,41 +1644,52 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
     }
 }
 
-// Workspace of the warp, in this order (every part rounded up to 256 bytes):
-//   hinv_pad [cells][10] f64 | lut [final_h + final_w] i32 | frec [(rows + 1)(cols + 1)][3] float4 |
-//   fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
+// Workspace of the warp (every part rounded up to 256 bytes): first what depends on the mesh edges, the canvas and
+// the offsets only and is SHARED by all pairs of a batch,
+//   lut [final_h + final_w] i32 | fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
+// then, per pair of the batch, what depends on that pair's H grid,
+//   hinv_pad [cells][10] f64 | frec [(rows + 1)(cols + 1)][3] float4
 // frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
 // `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row,
 // float bits of dy}, dx / dy = signed distance from the cell's anchor (its middle pixel); pixels that are not
 // inside an ordinary cell point at the extra row / column.
 struct WarpWork {
-    double *hinv_pad;
+    double *hinv_pad;   // pair 0; pair k at + k * hinv_stride doubles
     int *lut;
-    float4 *frec;
+    float4 *frec;       // pair 0; pair k at + k * frec_stride float4
     unsigned *fcol;
     uint2 *frow;
     int *src_rows;      // [rows][2] source-row interval per cell row, then 1 flag word (bit 0: irregular mesh)
+    long long hinv_stride, frec_stride;
     size_t bytes;
+};
+
+// distance between consecutive pairs of a batch: bytes for the images, doubles / float4 for the per-pair tables
+struct WarpStrides {
+    long long img, out, center, hinv, frec;
 };
 
 __host__ __device__ inline size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 
-inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int final_w, int final_h) {
+inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int final_w, int final_h, int batch = 1) {
     WarpWork w;
     char *p = (char *)base;
     const size_t cells = (size_t)mesh_rows * mesh_cols;
-    w.hinv_pad = (double *)p;
-    p += round256(cells * APAP_HINV_STRIDE * sizeof(double));
     w.lut = (int *)p;
     p += round256(((size_t)final_w + final_h) * sizeof(int));
-    w.frec = (float4 *)p;
-    p += round256(((size_t)mesh_rows + 1) * ((size_t)mesh_cols + 1) * 3 * sizeof(float4));
     w.fcol = (unsigned *)p;
     p += round256((((size_t)final_w + 3) / 4 * 4) * sizeof(unsigned));
     w.frow = (uint2 *)p;
     p += round256((size_t)final_h * sizeof(uint2));
     w.src_rows = (int *)p;
     p += round256(((size_t)mesh_rows * 2 + 2) * sizeof(int));
+    const size_t hinv_bytes = round256(cells * APAP_HINV_STRIDE * sizeof(double));
+    const size_t frec_bytes = round256(((size_t)mesh_rows + 1) * ((size_t)mesh_cols + 1) * 3 * sizeof(float4));
+    w.hinv_pad = (double *)p;
+    w.frec = (float4 *)(p + hinv_bytes);
+    w.hinv_stride = (long long)((hinv_bytes + frec_bytes) / sizeof(double));
+    w.frec_stride = (long long)((hinv_bytes + frec_bytes) / sizeof(float4));
+    p += (hinv_bytes + frec_bytes) * (size_t)(batch < 1 ? 1 : batch);
     w.bytes = (size_t)(p - (char *)base);
     return w;
 }
@@ -1692,7 +1703,11 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
                                                     int mesh_rows, int mesh_cols, int final_w, int final_h,
                                                     int *__restrict__ lut, int *status, int off_x, int off_y,
                                                     float4 *__restrict__ frec, unsigned *__restrict__ fcol,
-                                                    uint2 *__restrict__ frow, int *__restrict__ src_rows) {
+                                                    uint2 *__restrict__ frow, int *__restrict__ src_rows,
+                                                    long long hinv_stride, long long frec_stride) {
+    // grid.y = pair of a batch (every pair has the same mesh and canvas: the lookup tables are built once, by
+    // y = 0); blocks [0, inv_blocks) are the per-cell half - what depends on the H grid -, the rest the tables.
+    // Either half may be absent from a launch (inv_blocks = 0, or a grid of inv_blocks blocks).
     // src_rows (optional; the host-buffer warp schedules its upload / warp / download bands with it): per
     // cell row the interval of source rows its pixels can read, [2 r] pre-set to INT_MAX-like, [2 r + 1] to
     // INT_MIN-like by the caller; word [2 rows]: bit 0 set when some canvas pixel is not inside an ordinary cell
@@ -1703,6 +1718,11 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         // one thread per entry of the (rows + 1) x (cols + 1) record table; the extra row and column are the
         // everything-in-doubt records.  (Inverting each cell twice, in two waves - one storing the inverse, one
         // building the record - to shorten the dependent chain measured slower: 8.6 vs 7.6 us.)
+        const size_t pair = blockIdx.y;
+        H += pair * (size_t)cells * 9;
+        hinv_pad += pair * hinv_stride;
+        frec += pair * frec_stride;
+        if (hinv_dense) hinv_dense += pair * (size_t)cells * 9;
         const int e = blockIdx.x * 256 + tid;
         const int er = e / (mesh_cols + 1), ec = e - er * (mesh_cols + 1);
         if (er > mesh_rows) return;
@@ -1739,6 +1759,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
                     (double)(sy - sy / 2), frec + (size_t)e * 3, src_rows ? src_rows + 2 * er : nullptr);
         return;
     }
+    if (blockIdx.y != 0) return;
     const int row_blocks = (final_h + 1023) / 1024;
     const int b = blockIdx.x - inv_blocks;
     const bool is_row = b < row_blocks;
@@ -1862,9 +1883,17 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
                                               const int *__restrict__ lut, int final_w, int final_h,
                                               int off_x, int off_y, uint8_t *__restrict__ out,
                                               const uint8_t *__restrict__ center, int center_h, int center_w,
-                                              int row_begin, int row_count) {
+                                              int row_begin, int row_count, WarpStrides st) {
     // The launch covers canvas rows [row_begin, row_begin + row_count) - the whole canvas,
     // or one rank's band when a pair is sharded over GPUs; `out` points at the band's first row.
+    // grid.z = pair of a batch (one mesh and canvas geometry, its own image, grid and canvas).
+    {
+        const long long pair = blockIdx.z;
+        img += pair * st.img;
+        out += pair * st.out;
+        if (kBlend) center += pair * st.center;
+        hinv_pad += pair * st.hinv;
+    }
     // 32-bit pixel indices (the launcher refuses canvases of 2^31 pixels or more): a
     // 64-bit division here expands into ~100 instructions with branches
     const unsigned total = (unsigned)final_w * (unsigned)row_count;
@@ -1985,8 +2014,15 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
                                                    const int *__restrict__ lut, int final_w, int final_h,
                                                    int off_x, int off_y, uint8_t *__restrict__ out,
                                                    const uint8_t *__restrict__ center, int center_h, int center_w,
-                                                   int row_begin, int row_count) {
+                                                   int row_begin, int row_count, WarpStrides st) {
     // (Renumbering the blocks so that each XCD owns a band of rows was measured: no change.)
+    {
+        const long long pair = blockIdx.z;      // pair of a batch
+        img += pair * st.img;
+        out += pair * st.out;
+        if (kBlend) center += pair * st.center;
+        hinv_pad += pair * st.hinv;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
@@ -2167,7 +2203,15 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
                                                    int final_w, int final_h, int off_x, int off_y,
                                                    uint8_t *__restrict__ out, const uint8_t *__restrict__ center,
-                                                   int center_h, int center_w, int row_begin, int row_count) {
+                                                   int center_h, int center_w, int row_begin, int row_count, WarpStrides st) {
+    {
+        const long long pair = blockIdx.z;      // pair of a batch: its own image, canvas, inverses and records
+        img += pair * st.img;
+        out += pair * st.out;
+        if (kBlend) center += pair * st.center;
+        hinv_pad += pair * st.hinv;
+        frec += pair * st.frec;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
@@ -2621,94 +2665,136 @@ int apap_weights_device(apap_ctx *ctx, const double *d_table, int n, const doubl
     return APAP_OK;
 }
 
+size_t apap_warp_batch_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h, int batch) {
+    if (mesh_rows < 1 || mesh_cols < 1 || final_w < 1 || final_h < 1 || batch < 1) return 0;
+    return warp_work_layout(nullptr, mesh_rows, mesh_cols, final_w, final_h, batch).bytes;
+}
+
 size_t apap_warp_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h) {
-    if (mesh_rows < 1 || mesh_cols < 1 || final_w < 1 || final_h < 1) return 0;
-    return warp_work_layout(nullptr, mesh_rows, mesh_cols, final_w, final_h).bytes;
+    return apap_warp_batch_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h, 1);
 }
 
 }  // extern "C"
 
+namespace {
+
+// Everything a warp launch needs; the entry points below fill it in.  `batch` pairs share the mesh edges, the canvas
+// size and the offsets; pair k reads image img + k img_stride (bytes), grid Hfwd + k cells 9, and writes canvas
+// out + k out_stride (bytes) - out points at row `row_begin` of pair 0's canvas.
+struct WarpArgs {
+    const uint8_t *img = nullptr;
+    long long img_stride = 0;
+    int img_h = 0, img_w = 0;
+    const uint8_t *center = nullptr;
+    long long center_stride = 0;
+    int center_h = 0, center_w = 0;
+    const void *Hfwd = nullptr;
+    int mesh_rows = 0, mesh_cols = 0;
+    const double *mesh_w = nullptr;
+    int n_w = 0;
+    const double *mesh_h = nullptr;
+    int n_h = 0;
+    int final_w = 0, final_h = 0, off_x = 0, off_y = 0;
+    uint8_t *out = nullptr;
+    long long out_stride = 0;
+    void *Hinv_out = nullptr;
+    int batch = 1;
+    void *work = nullptr;
+    size_t work_bytes = 0;
+    int *status = nullptr;
+    void *stream = nullptr;
+    int row_begin = 0, row_count = 0;
+    int phase = APAP_WARP_ALL;
+    int **src_rows = nullptr;
+};
+
 template <typename T>
-static int warp_prologue(apap_ctx *ctx, const T *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
-                         int n_w, const double *d_mesh_h, int n_h, int final_w, int final_h,
-                         T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                         hipStream_t s, int off_x, int off_y, WarpWork *ww, bool *fast_tables, int phase = apap::kWarpSetup,
-                         bool want_src_rows = false) {
-    if (!d_Hfwd || !d_mesh_w || !d_mesh_h || !d_work || !d_status)
-        return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
-    if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1)
+int warp_prologue(apap_ctx *ctx, const WarpArgs &a, WarpWork *ww, bool *fast_tables) {
+    if (!a.mesh_w || !a.mesh_h || !a.work || !a.status) return apap::fail(APAP_ERR_INVALID_ARG, "warp: null device pointer");
+    if (a.mesh_rows < 1 || a.mesh_cols < 1 || a.n_w < 1 || a.n_h < 1 || a.final_w < 1 || a.final_h < 1 || a.batch < 1 || a.batch > 65535)
         return apap::fail(APAP_ERR_INVALID_ARG, "warp: bad size");
-    const size_t need = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
-    if (work_bytes < need) return apap::fail(APAP_ERR_WORKSPACE, "warp: workspace %zu < %zu bytes", work_bytes, need);
-    const int cells = mesh_rows * mesh_cols;
-    *ww = warp_work_layout(d_work, mesh_rows, mesh_cols, final_w, final_h);
-    *fast_tables = n_w <= kMaxEdges && n_h <= kMaxEdges && mesh_rows < 65535 && mesh_cols < 65535;
-    if (!(phase & apap::kWarpSetup)) return APAP_OK;     // the tables of an earlier call on this workspace are used
+    const size_t need = apap_warp_batch_workspace_bytes(a.mesh_rows, a.mesh_cols, a.final_w, a.final_h, a.batch);
+    if (a.work_bytes < need) return apap::fail(APAP_ERR_WORKSPACE, "warp: workspace %zu < %zu bytes", a.work_bytes, need);
+    const int cells = a.mesh_rows * a.mesh_cols;
+    *ww = warp_work_layout(a.work, a.mesh_rows, a.mesh_cols, a.final_w, a.final_h, a.batch);
+    *fast_tables = a.n_w <= kMaxEdges && a.n_h <= kMaxEdges && a.mesh_rows < 65535 && a.mesh_cols < 65535;
+    const bool geometry = (a.phase & APAP_WARP_GEOMETRY) != 0, per_cell = (a.phase & APAP_WARP_CELLS) != 0;
+    if (!geometry && !per_cell) return APAP_OK;     // the tables an earlier call left in this workspace are used
+    if (per_cell && !a.Hfwd) return apap::fail(APAP_ERR_INVALID_ARG, "warp: null H grid");
+    hipStream_t s = (hipStream_t)a.stream;
+    const T *Hfwd = (const T *)a.Hfwd;
+    T *Hinv_out = (T *)a.Hinv_out;
     if (*fast_tables) {
-        // one launch: cell inverses + fast records + lookup tables (reported under the INVERT slot)
+        // one launch: cell inverses + fast records (grid.y = pair) + lookup tables (reported under the INVERT slot)
         ProfScope prof(ctx, APAP_PROF_INVERT, s);
-        const int inv_blocks = (int)(((size_t)(mesh_rows + 1) * (mesh_cols + 1) + 255) / 256);
-        const int lut_blocks = (final_h + 1023) / 1024 + (final_w + 1023) / 1024;
-        hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks), dim3(256), 0, s, d_Hfwd, cells, ww->hinv_pad,
-                           d_Hinv_out, inv_blocks, d_mesh_w, n_w, d_mesh_h, n_h, mesh_rows, mesh_cols, final_w,
-                           final_h, ww->lut, d_status, off_x, off_y, ww->frec, ww->fcol, ww->frow,
-                           want_src_rows ? ww->src_rows : (int *)nullptr);
+        const int inv_blocks = per_cell ? (int)(((size_t)(a.mesh_rows + 1) * (a.mesh_cols + 1) + 255) / 256) : 0;
+        const int lut_blocks = geometry ? (a.final_h + 1023) / 1024 + (a.final_w + 1023) / 1024 : 0;
+        hipLaunchKernelGGL(k_warp_setup<T>, dim3(inv_blocks + lut_blocks, per_cell ? a.batch : 1), dim3(256), 0, s, Hfwd, cells,
+                           ww->hinv_pad, Hinv_out, inv_blocks, a.mesh_w, a.n_w, a.mesh_h, a.n_h, a.mesh_rows, a.mesh_cols,
+                           a.final_w, a.final_h, ww->lut, a.status, a.off_x, a.off_y, ww->frec, ww->fcol, ww->frow,
+                           a.src_rows && geometry && per_cell && a.batch == 1 ? ww->src_rows : (int *)nullptr, ww->hinv_stride,
+                           ww->frec_stride);
     } else {
-        {
+        if (per_cell) {
             ProfScope prof(ctx, APAP_PROF_INVERT, s);
-            hipLaunchKernelGGL(k_invert_cells<T>, dim3((cells + 255) / 256), dim3(256), 0, s, d_Hfwd, cells, ww->hinv_pad,
-                               d_Hinv_out, d_status);
+            for (int k = 0; k < a.batch; ++k)
+                hipLaunchKernelGGL(k_invert_cells<T>, dim3((cells + 255) / 256), dim3(256), 0, s, Hfwd + (size_t)k * cells * 9, cells,
+                                   ww->hinv_pad + k * ww->hinv_stride, Hinv_out ? Hinv_out + (size_t)k * cells * 9 : (T *)nullptr,
+                                   a.status);
         }
-        {
+        if (geometry) {
             ProfScope prof(ctx, APAP_PROF_LUT, s);
-            hipLaunchKernelGGL(k_cell_lut, dim3((final_w + final_h + 255) / 256), dim3(256), 0, s, d_mesh_w, n_w,
-                               d_mesh_h, n_h, mesh_rows, mesh_cols, final_w, final_h, ww->lut, d_status);
+            hipLaunchKernelGGL(k_cell_lut, dim3((a.final_w + a.final_h + 255) / 256), dim3(256), 0, s, a.mesh_w, a.n_w,
+                               a.mesh_h, a.n_h, a.mesh_rows, a.mesh_cols, a.final_w, a.final_h, ww->lut, a.status);
         }
     }
     return APAP_OK;
 }
 
 template <typename T>
-static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
-                     int center_w, const T *d_Hfwd, int mesh_rows,
-                     int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
-                     int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
-                     T *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
-                     void *stream, int row_begin, int row_count, int phase = apap::kWarpSetup | apap::kWarpRows,
-                     int **d_src_rows = nullptr) {
-    if (!d_img || !d_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
-    if (row_begin < 0 || row_count < 0 || (long long)row_begin + row_count > final_h)
+int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
+    const bool gather = (a.phase & APAP_WARP_GATHER) != 0;
+    if (a.phase < 1 || a.phase > APAP_WARP_ALL) return apap::fail(APAP_ERR_INVALID_ARG, "warp: phases %d", a.phase);
+    if (gather && (!a.img || !a.out)) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: null image pointer");
+    if (a.row_begin < 0 || a.row_count < 0 || (long long)a.row_begin + a.row_count > a.final_h)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_rows_device: rows [%d, %d) outside the canvas of %d rows",
-                          row_begin, row_begin + row_count, final_h);
-    if (d_center) {
+                          a.row_begin, a.row_begin + a.row_count, a.final_h);
+    if (gather && a.center) {
         // the reference pastes with a numpy slice assignment, which raises when the
         // centre image does not fit the canvas at the offsets
-        if (center_h < 1 || center_w < 1 || (size_t)center_h * center_w < 2 || off_x < 0 || off_y < 0 ||
-            (long long)off_y + center_h > final_h || (long long)off_x + center_w > final_w)
+        if (a.center_h < 1 || a.center_w < 1 || (size_t)a.center_h * a.center_w < 2 || a.off_x < 0 || a.off_y < 0 ||
+            (long long)a.off_y + a.center_h > a.final_h || (long long)a.off_x + a.center_w > a.final_w)
             return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: centre image %dx%d at (%d,%d) does not fit canvas %dx%d",
-                              center_w, center_h, off_x, off_y, final_w, final_h);
-        if ((unsigned long long)center_h * (unsigned long long)center_w * 3ull >= (1ull << 32))
+                              a.center_w, a.center_h, a.off_x, a.off_y, a.final_w, a.final_h);
+        if ((unsigned long long)a.center_h * (unsigned long long)a.center_w * 3ull >= (1ull << 32))
             return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: centre image of 4 GiB or more");
     }
-    if (img_h < 1 || img_w < 1 || (size_t)img_h * img_w < 2)
-        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size (need at least 2 pixels)");
-    if ((unsigned long long)img_h * (unsigned long long)img_w * 3ull >= (1ull << 32))
-        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: image of 4 GiB or more");
-    if ((unsigned long long)final_w * (unsigned long long)final_h >= (1ull << 31))
+    if (gather) {
+        if (a.img_h < 1 || a.img_w < 1 || (size_t)a.img_h * a.img_w < 2)
+            return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: bad image size (need at least 2 pixels)");
+        if ((unsigned long long)a.img_h * (unsigned long long)a.img_w * 3ull >= (1ull << 32))
+            return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: image of 4 GiB or more");
+    }
+    if ((unsigned long long)a.final_w * (unsigned long long)a.final_h >= (1ull << 31))
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: canvas of 2^31 pixels or more");
-    if ((unsigned long long)mesh_rows * (unsigned long long)mesh_cols * APAP_HINV_STRIDE * sizeof(double) >= (1ull << 32))
+    if ((unsigned long long)a.mesh_rows * (unsigned long long)a.mesh_cols * APAP_HINV_STRIDE * sizeof(double) >= (1ull << 32))
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_device: mesh of 53 million cells or more");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = (hipStream_t)a.stream;
     WarpWork ww;
     bool fast_tables;
-    const int rc = warp_prologue<T>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                    d_Hinv_out, d_work, work_bytes, d_status, s, off_x, off_y, &ww, &fast_tables, phase,
-                                    d_src_rows != nullptr);
+    const int rc = warp_prologue<T>(ctx, a, &ww, &fast_tables);
     if (rc != APAP_OK) return rc;
-    if (d_src_rows) *d_src_rows = fast_tables ? ww.src_rows : nullptr;
+    if (a.src_rows) *a.src_rows = fast_tables && a.batch == 1 ? ww.src_rows : nullptr;
     double *hinv_pad = ww.hinv_pad;
     int *lut = ww.lut;
-    if (row_count == 0 || !(phase & apap::kWarpRows)) return APAP_OK;  // an empty band: only the set-up kernel ran
+    if (a.row_count == 0 || !gather) return APAP_OK;  // an empty band: only the set-up kernel ran
+    const uint8_t *d_img = a.img, *d_center = a.center;
+    uint8_t *d_out = a.out;
+    const int img_h = a.img_h, img_w = a.img_w, center_h = a.center_h, center_w = a.center_w, mesh_rows = a.mesh_rows,
+              mesh_cols = a.mesh_cols, final_w = a.final_w, final_h = a.final_h, off_x = a.off_x, off_y = a.off_y,
+              row_begin = a.row_begin, row_count = a.row_count;
+    const unsigned batch = (unsigned)a.batch;
+    const WarpStrides st{a.img_stride, a.out_stride, a.center_stride, ww.hinv_stride, ww.frec_stride};
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
     // APAP_OPT_WARP_ROWS (experiments): 0 = flat-order kernel, 2 / 4 / 8 = row strips of that many
@@ -2729,16 +2815,16 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
 #define APAP_K3_BLOCK 256
 #endif
         constexpr int kWpb = APAP_K3_BLOCK / 64;      // waves (= strips) per block
-        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + kWpb * rows - 1) / (kWpb * rows)));
+        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + kWpb * rows - 1) / (kWpb * rows)), batch);
 #define APAP_LAUNCH_FAST(R)                                                                                          \
     if (d_center)                                                                                                    \
         hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out, d_center,           \
-                           center_h, center_w, row_begin, row_count);                                                \
+                           center_h, center_w, row_begin, row_count, st);                                            \
     else                                                                                                             \
         hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
-                           (const uint8_t *)nullptr, 0, 0, row_begin, row_count)
+                           (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st)
         if (rows == 4) { APAP_LAUNCH_FAST(4); }
         else if (rows == 8) { APAP_LAUNCH_FAST(8); }
         else { APAP_LAUNCH_FAST(2); }
@@ -2746,43 +2832,72 @@ static int warp_impl(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
     } else if (strips) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;  // rows per wave: instantiated for 2, 4, 8
-        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)));
+        const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + 4 * rows - 1) / (4 * rows)), batch);
 #define APAP_LAUNCH_ROWS(R)                                                                                          \
     if (d_center)                                                                                                    \
         hipLaunchKernelGGL((k_warp_rows<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols,  \
                            lut, final_w, final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin,      \
-                           row_count);                                                                                    \
+                           row_count, st);                                                                                \
     else                                                                                                             \
         hipLaunchKernelGGL((k_warp_rows<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, \
                            lut, final_w, final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin,    \
-                           row_count)
+                           row_count, st)
         if (rows == 4) { APAP_LAUNCH_ROWS(4); }
         else if (rows == 8) { APAP_LAUNCH_ROWS(8); }
         else { APAP_LAUNCH_ROWS(2); }
 #undef APAP_LAUNCH_ROWS
     } else {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
-        const dim3 grid((unsigned)((threads + 255) / 256));
+        const dim3 grid((unsigned)((threads + 255) / 256), 1, batch);
         if (d_center)
             hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin, row_count);
+                               final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin, row_count, st);
         else
             hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin, row_count);
+                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");
     return APAP_OK;
 }
 
+// the argument block of the single-pair entry points
+WarpArgs single_pair(const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h, int center_w,
+                     const void *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
+                     int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out, void *d_Hinv_out, void *d_work,
+                     size_t work_bytes, int *d_status, void *stream, int row_begin, int row_count) {
+    WarpArgs a;
+    a.img = d_img; a.img_h = img_h; a.img_w = img_w;
+    a.center = d_center; a.center_h = center_h; a.center_w = center_w;
+    a.Hfwd = d_Hfwd; a.mesh_rows = mesh_rows; a.mesh_cols = mesh_cols;
+    a.mesh_w = d_mesh_w; a.n_w = n_w; a.mesh_h = d_mesh_h; a.n_h = n_h;
+    a.final_w = final_w; a.final_h = final_h; a.off_x = off_x; a.off_y = off_y;
+    a.out = d_out; a.Hinv_out = d_Hinv_out;
+    a.work = d_work; a.work_bytes = work_bytes; a.status = d_status; a.stream = stream;
+    a.row_begin = row_begin; a.row_count = row_count;
+    return a;
+}
+
+}  // namespace
+
 namespace apap {
 int warp_phase(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h, int center_w,
                const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h,
                int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out_band, float *d_Hinv_out, void *d_work,
                size_t work_bytes, int *d_status, void *stream, int row_begin, int row_count, int phase, int **d_src_rows) {
-    return warp_impl<float>(ctx, d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
-                            d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out_band, d_Hinv_out, d_work, work_bytes, d_status,
-                            stream, row_begin, row_count, phase, d_src_rows);
+    WarpArgs a = single_pair(d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
+                             d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out_band, d_Hinv_out, d_work, work_bytes, d_status,
+                             stream, row_begin, row_count);
+    a.src_rows = d_src_rows;
+    if (phase == 0) {       // where the source-row intervals of this workspace live, nothing launched
+        if (d_src_rows) {
+            const bool fast = n_w <= kMaxEdges && n_h <= kMaxEdges && mesh_rows < 65535 && mesh_cols < 65535;
+            *d_src_rows = fast ? warp_work_layout(d_work, mesh_rows, mesh_cols, final_w, final_h).src_rows : nullptr;
+        }
+        return APAP_OK;
+    }
+    a.phase = phase;
+    return warp_impl<float>(ctx, a);
 }
 }  // namespace apap
 
@@ -2793,26 +2908,27 @@ int apap_warp_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, 
                      int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *d_out,
                      float *d_Hinv_out, void *d_work, size_t work_bytes, int *d_status,
                      void *stream) {
-    return warp_impl<float>(ctx, d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
-                     final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream, 0, final_h);
+    return warp_impl<float>(ctx, single_pair(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h,
+                                             n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status,
+                                             stream, 0, final_h));
 }
 
 int apap_warp_f64_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const double *d_Hfwd, int mesh_rows,
                          int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h, int final_w,
                          int final_h, int off_x, int off_y, uint8_t *d_out, double *d_Hinv_out, void *d_work,
                          size_t work_bytes, int *d_status, void *stream) {
-    return warp_impl<double>(ctx, d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h,
-                             n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status, stream, 0,
-                             final_h);
+    return warp_impl<double>(ctx, single_pair(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
+                                              d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes,
+                                              d_status, stream, 0, final_h));
 }
 
 int apap_warp_rows_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const float *d_Hfwd, int mesh_rows,
                           int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h,
                           int final_w, int final_h, int off_x, int off_y, int row_begin, int row_count,
                           uint8_t *d_out_band, void *d_work, size_t work_bytes, int *d_status, void *stream) {
-    return warp_impl<float>(ctx, d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h,
-                     final_w, final_h, off_x, off_y, d_out_band, nullptr, d_work, work_bytes, d_status, stream, row_begin,
-                     row_count);
+    return warp_impl<float>(ctx, single_pair(d_img, img_h, img_w, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h,
+                                             n_h, final_w, final_h, off_x, off_y, d_out_band, nullptr, d_work, work_bytes, d_status,
+                                             stream, row_begin, row_count));
 }
 
 int apap_stitch_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,
@@ -2821,9 +2937,32 @@ int apap_stitch_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w
                        int final_h, int off_x, int off_y, uint8_t *d_out, float *d_Hinv_out, void *d_work,
                        size_t work_bytes, int *d_status, void *stream) {
     if (!d_center) return apap::fail(APAP_ERR_INVALID_ARG, "apap_stitch_device: null centre image");
-    return warp_impl<float>(ctx, d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
-                     d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes, d_status,
-                     stream, 0, final_h);
+    return warp_impl<float>(ctx, single_pair(d_img, img_h, img_w, d_center, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w,
+                                             n_w, d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_out, d_Hinv_out, d_work, work_bytes,
+                                             d_status, stream, 0, final_h));
+}
+
+int apap_warp_batch_device(apap_ctx *ctx, const uint8_t *d_imgs, long long img_stride, int img_h, int img_w,
+                           const uint8_t *d_centers, long long center_stride, int center_h, int center_w,
+                           const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w,
+                           const double *d_mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
+                           int row_begin, int row_count, uint8_t *d_outs, long long out_stride, float *d_Hinv_out,
+                           int batch, int phases, void *d_work, size_t work_bytes, int *d_status, void *stream) {
+    if (batch < 1 || batch > 65535) return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_batch_device: batch=%d", batch);
+    if (img_stride < 0 || out_stride < 0 || center_stride < 0)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_batch_device: negative stride");
+    if (batch > 1 && (phases & APAP_WARP_GATHER) && out_stride < (long long)row_count * final_w * 3)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_warp_batch_device: canvases overlap (stride %lld < %lld bytes)", out_stride,
+                          (long long)row_count * final_w * 3);
+    WarpArgs a = single_pair(d_imgs, img_h, img_w, d_centers, center_h, center_w, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w,
+                             d_mesh_h, n_h, final_w, final_h, off_x, off_y, d_outs, d_Hinv_out, d_work, work_bytes, d_status,
+                             stream, row_begin, row_count);
+    a.img_stride = img_stride;
+    a.center_stride = center_stride;
+    a.out_stride = out_stride;
+    a.batch = batch;
+    a.phase = phases;
+    return warp_impl<float>(ctx, a);
 }
 
 int apap_warp_coords_device(apap_ctx *ctx, const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w,
@@ -2834,8 +2973,10 @@ int apap_warp_coords_device(apap_ctx *ctx, const float *d_Hfwd, int mesh_rows, i
     hipStream_t s = (hipStream_t)stream;
     WarpWork ww;
     bool fast_tables;
-    const int rc = warp_prologue<float>(ctx, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w, final_h,
-                                        nullptr, d_work, work_bytes, d_status, s, off_x, off_y, &ww, &fast_tables);
+    WarpArgs a = single_pair(nullptr, 0, 0, nullptr, 0, 0, d_Hfwd, mesh_rows, mesh_cols, d_mesh_w, n_w, d_mesh_h, n_h, final_w,
+                             final_h, off_x, off_y, nullptr, nullptr, d_work, work_bytes, d_status, stream, 0, final_h);
+    a.phase = APAP_WARP_GEOMETRY | APAP_WARP_CELLS;
+    const int rc = warp_prologue<float>(ctx, a, &ww, &fast_tables);
     if (rc != APAP_OK) return rc;
     double *hinv_pad = ww.hinv_pad;
     int *lut = ww.lut;

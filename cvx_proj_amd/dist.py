@@ -95,6 +95,43 @@ def hip_solve_batch(tables, denorms, vertices, gamma, sigma, ctx=None):
     return H
 
 
+def hip_warp_batch(imgs, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, shape, out=None, centers=None, ctx=None,
+                   work=None, status=None, phases=_native.WARP_ALL, rows=None, hinv_out=None):
+    """Backward warp of a BATCH of independent pairs in one set of launches (``apap_warp_batch_device``, grid.z = pair):
+    ``imgs`` (B, h, w, 3) uint8 - or (h, w, 3): one image for every pair -, ``H`` (B, cells, 9) float32 (what
+    ``hip_solve_batch`` returns), one set of edges, canvas size and offsets for all -> canvases (B, final_h, final_w, 3).
+    ``centers`` (B, ch, cw, 3) or (ch, cw, 3): the fused stitch (warp + paste + uniform_blend).  ``phases``: which of
+    geometry tables / per-cell set-up / gather run on ``work`` (a caller that keeps ``work`` runs the geometry once).
+    ``rows`` = (row_begin, row_count): a band of every canvas; ``out`` is then (B, row_count, final_w, 3)."""
+    if not H.is_cuda:
+        raise _native.ApapError(_native.ERR_NO_DEVICE, "hip_warp_batch needs CUDA/HIP tensors; there is no CPU fallback")
+    mrows, mcols = shape
+    batch = H.shape[0]
+    dev = H.device
+    row_begin, row_count = (0, final_h) if rows is None else rows
+    one_img = imgs.dim() == 3
+    ih, iw = (imgs.shape[0], imgs.shape[1]) if one_img else (imgs.shape[1], imgs.shape[2])
+    if out is None:
+        out = torch.empty((batch, row_count, final_w, 3), dtype=torch.uint8, device=dev)
+    nbytes = _native.lib().apap_warp_batch_workspace_bytes(mrows, mcols, final_w, final_h, batch)
+    if work is None or work.numel() < nbytes:
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    c_ptr, c_stride, ch, cw = None, 0, 0, 0
+    if centers is not None:
+        one_c = centers.dim() == 3
+        ch, cw = (centers.shape[0], centers.shape[1]) if one_c else (centers.shape[1], centers.shape[2])
+        c_ptr, c_stride = centers.data_ptr(), 0 if one_c else ch * cw * 3
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _native.check(_native.lib().apap_warp_batch_device(
+        _native._h(ctx), imgs.data_ptr(), 0 if one_img else ih * iw * 3, ih, iw, c_ptr, c_stride, ch, cw, H.data_ptr(), mrows, mcols,
+        mesh_w.data_ptr(), mesh_w.numel(), mesh_h.data_ptr(), mesh_h.numel(), final_w, final_h, off_x, off_y, row_begin, row_count,
+        out.data_ptr(), row_count * final_w * 3, None if hinv_out is None else hinv_out.data_ptr(), batch, int(phases),
+        work.data_ptr(), work.numel(), status.data_ptr(), ctypes.c_void_p(stream)))
+    return out, status
+
+
 class ShardedSolver:
     """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
 
@@ -365,3 +402,52 @@ def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
         return None
     rows, cols = pairs[0].vertices.shape[:2]
     return [out[k % world][k // world].cpu().numpy().reshape(rows, cols, 3, 3) for k in range(len(pairs))]
+
+
+def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=False, ctx=None):
+    """The warp half of independent pairs (BASELINE config 5; the reference runs apap.py:186-217 once per pair): the
+    pairs are dealt round-robin to the ranks like ``solve_pairs`` deals them, every rank warps ITS pairs in one batched
+    set of launches (grid.z = pair), no collective on the data path.  ``grids[k]`` is pair k's H grid (rows, cols, 3, 3)
+    - only the entries of this rank's pairs are read (None elsewhere is fine).  All pairs must share the image size, the
+    mesh and the canvas geometry.  Returns ``{pair index: canvas (final_h, final_w, 3) uint8 tensor on dev}`` for this
+    rank's pairs - 27 MB per 4K canvas: they stay where they were computed - or, with ``gather=True``, on rank 0 the
+    list of all canvases as numpy arrays in input order (``None`` on the other ranks): for tests and small batches."""
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    mine = list(range(rank, len(pairs), world))
+    p0 = pairs[0]
+    for p in pairs:
+        if (p.shape, p.final_w, p.final_h, p.off_x, p.off_y) != (p0.shape, p0.final_w, p0.final_h, p0.off_x, p0.off_y) \
+                or not np.array_equal(p.mesh, p0.mesh):
+            raise ValueError("warp_pairs: the pairs of a batch must share image size, mesh edges, canvas size and offsets")
+    rows, cols = p0.vertices.shape[:2]
+    canv = {}
+    if mine:
+        imgs = torch.stack([torch.from_numpy(np.ascontiguousarray(pairs[k].img)) for k in mine]).to(dev)
+        H = torch.stack([torch.from_numpy(np.ascontiguousarray(grids[k], dtype=np.float32).reshape(rows * cols, 9)) for k in mine]).to(dev)
+        mesh_w = torch.from_numpy(np.ascontiguousarray(p0.mesh[0], dtype=np.float64)).to(dev)
+        mesh_h = torch.from_numpy(np.ascontiguousarray(p0.mesh[1], dtype=np.float64)).to(dev)
+        kw = {"ctx": ctx} if ctx is not None else {}
+        out, status = warp_fn(imgs, H, mesh_w, mesh_h, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols), **kw)
+        if status is not None and int(status.cpu()[0]) != 0:
+            code = _native.ERR_SINGULAR if int(status.cpu()[0]) & 1 else _native.ERR_INDEX
+            raise _native._ERROR_CLASSES[code](code, "warp_pairs: device status word %d" % int(status.cpu()[0]))
+        canv = {k: out[i] for i, k in enumerate(mine)}
+    if not gather:
+        return canv
+    per_rank = (len(pairs) + world - 1) // world
+    buf = torch.zeros((per_rank, p0.final_h, p0.final_w, 3), dtype=torch.uint8, device=dev)
+    for i, k in enumerate(mine):
+        buf[i].copy_(canv[k])
+    if dist is None or world == 1:
+        return [buf[k].cpu().numpy() for k in range(len(pairs))]
+    if dist.get_backend() == "nccl":
+        allbuf = torch.zeros((world,) + tuple(buf.shape), dtype=buf.dtype, device=dev)
+        dist.all_gather_into_tensor(allbuf.view((-1,) + tuple(buf.shape[1:])), buf)
+        got = list(allbuf) if rank == 0 else None
+    else:
+        got = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, got, dst=0)
+    if rank != 0:
+        return None
+    return [got[k % world][k // world].cpu().numpy() for k in range(len(pairs))]

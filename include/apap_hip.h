@@ -82,8 +82,8 @@ extern "C" {
  * float* where the context goes.  Such a caller must refuse to run: check apap_abi_version() ==
  * APAP_ABI_VERSION once after loading (cvx_proj_amd/_native.py does); a generation-1 library does not
  * export the symbol at all.  Bump on any change of an existing signature. */
-#define APAP_ABI_VERSION 3
-#define APAP_ABI_VERSION_STRING "0.3"
+#define APAP_ABI_VERSION 4
+#define APAP_ABI_VERSION_STRING "0.4"
 
 /* ---------------------------------------------------------------- diagnostics --- */
 const char *apap_last_error(void);
@@ -280,6 +280,35 @@ int apap_warp_rows_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int im
                           int mesh_cols, const double *d_mesh_w, int n_w, const double *d_mesh_h, int n_h,
                           int final_w, int final_h, int off_x, int off_y, int row_begin, int row_count,
                           uint8_t *d_out_band, void *d_work, size_t work_bytes, int *d_status, void *stream);
+
+/* The warp of a BATCH of independent pairs in one set of launches (BASELINE.json config 5: 64 pairs of one size; the
+ * reference runs apap.py:186-217 once per pair), and the general form of every warp entry point above.
+ * All pairs share the mesh edges, the canvas size and the offsets (pairs of one configuration do); pair k has its own
+ *   image   d_imgs + k * img_stride bytes (img_h x img_w x 3; stride 0 = one image for all),
+ *   centre  d_centers + k * center_stride bytes, or d_centers = NULL for the plain warp (non-NULL: the fused stitch),
+ *   grid    d_Hfwd + k * mesh_rows * mesh_cols * 9 floats (what apap_solve_batch_device writes),
+ *   canvas  d_outs + k * out_stride bytes, receiving rows [row_begin, row_begin + row_count) of its canvas,
+ *   inverse d_Hinv_out + k * mesh_rows * mesh_cols * 9 floats, when d_Hinv_out is not NULL.
+ * grid.z of the kernels is the pair: one set-up launch covers every pair's cells, one gather launch every canvas -
+ * 64 pairs fill the chip where one pair's ~9000 waves are 1.45 generations with idle set-up, ramp and tail.
+ * `phases`: which steps run on the workspace, any combination of
+ *   APAP_WARP_GEOMETRY  canvas row / column -> cell tables: depend on the edges, the canvas size and the offsets only;
+ *   APAP_WARP_CELLS     per-cell inverses and the float32 estimate's records: depend on the H grids (and the edges);
+ *   APAP_WARP_GATHER    K3, reading what the other two left in the workspace.
+ * A caller that warps many grids over one geometry runs GEOMETRY once and CELLS | GATHER per grid; APAP_WARP_ALL is the
+ * one-call form.  d_work: apap_warp_batch_workspace_bytes(...) bytes; the layout is private but stable between calls
+ * with equal (mesh_rows, mesh_cols, final_w, final_h, batch). */
+#define APAP_WARP_GEOMETRY 1
+#define APAP_WARP_CELLS 2
+#define APAP_WARP_GATHER 4
+#define APAP_WARP_ALL 7
+size_t apap_warp_batch_workspace_bytes(int mesh_rows, int mesh_cols, int final_w, int final_h, int batch);
+int apap_warp_batch_device(apap_ctx *ctx, const uint8_t *d_imgs, long long img_stride, int img_h, int img_w,
+                           const uint8_t *d_centers, long long center_stride, int center_h, int center_w,
+                           const float *d_Hfwd, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w,
+                           const double *d_mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
+                           int row_begin, int row_count, uint8_t *d_outs, long long out_stride, float *d_Hinv_out,
+                           int batch, int phases, void *d_work, size_t work_bytes, int *d_status, void *stream);
 
 /* Resident-data twin of apap_local_stitch. */
 int apap_stitch_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const uint8_t *d_center, int center_h,

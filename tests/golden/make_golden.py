@@ -20,6 +20,8 @@ script is how they were made.
     C4          every 8th mesh row of the 400 x 400 grid (~7 minutes of the reference's loop), SHA-256 of the
                 whole grid and of its in-place inverses, the 8K warped canvas (SHA-256 + every 256th row; ~3 min more)
     C5          eight of the 64 independent pairs (pairs 0, 1 in full, 2..7 every 4th mesh row + SHA-256 of the grid)
+    C5warp      c5_warp_k0 / c5_warp_k1: the reference's local_warp canvas of C5 pairs 0 and 1 (100 x 100 mesh over a 4K
+                canvas; SHA-256 + every 64th row) and the SHA-256 of the in-place inverses (~1 min each)
     illcond     illcond_ref: the six soak seeds of round 1 whose weighted systems are numerically rank-deficient
                 (gamma = 0, sigma <= 10 px, 5-17 keypoints), through the reference's APAP.local_homography;
                 illcond_truth: five seeds of round 2's soak on which the reference's float64 SVD itself is lost,
@@ -210,9 +212,10 @@ def illcond_truth_cases(ref_apap, name="illcond_truth.npz", cells_per_seed=10 **
     print(f"{name}: seeds {ILLCOND_TRUTH_SEEDS}")
 
 
-def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_every=1, seed_offset=0):
+def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_every=1, seed_offset=0, warp_only=False):
     """A BASELINE.json config: full H grid from the reference; for the warp, a SHA-256 of
-    the full canvas plus every ``warp_rows_every``-th row."""
+    the full canvas plus every ``warp_rows_every``-th row.  ``warp_only``: the file holds the warp half alone
+    (the grid is in the config's own fixture)."""
     sys.path.insert(0, REPO)
     from cvx_proj_amd.synth import config_pair
     p = config_pair(cfg, with_image=bool(warp_rows_every), seed_offset=seed_offset)
@@ -236,6 +239,9 @@ def config_case(ref_apap, ref_utils, cfg, name, warp_rows_every=16, keep_rows_ev
                    warped_rows=warped[::warp_rows_every].copy(),
                    warp_rows_every=warp_rows_every,
                    warped_sha256=np.frombuffer(hashlib.sha256(warped.tobytes()).digest(), dtype=np.uint8))
+    if warp_only:
+        out = {k: v for k, v in out.items() if k in ("final", "H_sha256", "Hinv_sha256", "warped_rows", "warp_rows_every",
+                                                     "warped_sha256")}
     np.savez_compressed(os.path.join(HERE, name), **out)
     print(f"{name}: {cfg} canvas {fw}x{fh} offsets ({ox},{oy}) cells {m}x{m}")
 
@@ -402,6 +408,10 @@ def main():
         for k in range(8):
             config_case(ref_apap, ref_utils, "C5", f"c5_ref_k{k}.npz", warp_rows_every=0, seed_offset=k,
                         keep_rows_every=1 if k < 2 else 4)
+    if "C5warp" in which:
+        # the warp half of config 5: the reference's pixel loop on pairs 0 and 1 (the image of pair k is drawn from seed 6400 + k)
+        for k in range(2):
+            config_case(ref_apap, ref_utils, "C5", f"c5_warp_k{k}.npz", warp_rows_every=64, seed_offset=k, warp_only=True)
     if "C4" in which:
         # ~7 minutes in the reference's Python loop; only every 8th mesh row is kept (720 KB)
         config_case(ref_apap, ref_utils, "C4", "c4_ref_rows8.npz", warp_rows_every=256, keep_rows_every=8)

@@ -6,21 +6,40 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_self_launch_two_ranks_gloo():
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_self_launch_ranks_gloo(ranks):
+    """2 ranks, and the 8 the driver's scaling run starts (the launch, the rendezvous and one collective; no GPU)."""
     env = dict(os.environ, APAP_BENCH_SELFTEST="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env,
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout                 # rank 0 only
     d = json.loads(lines[0])
-    assert d["selftest"] and d["n_gpus"] == 2 and d["sum"] == 3.0          # ranks 0 and 1 both contributed
-    assert d["ranks_env"][2] == "2" and d["ranks_env"][3] == "127.0.0.1"
+    assert d["selftest"] and d["n_gpus"] == ranks and d["sum"] == ranks * (ranks + 1) / 2     # every rank contributed
+    assert d["ranks_env"][2] == str(ranks) and d["ranks_env"][3] == "127.0.0.1"
+
+
+def test_a_failing_rank_exits_non_zero_with_evidence():
+    """A rank that cannot get a GPU (none here) must end the run with a non-zero code and say where it was - not hang,
+    not print a JSON line."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present: the run succeeds")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "APAP_BENCH_SELFTEST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "bench_failed" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
 
 
 def test_cpu_baseline_rows_on_a_small_config():

@@ -1,0 +1,197 @@
+"""The warp half of BASELINE config 5 (independent 4K pairs, 100 x 100 mesh; the reference runs
+apap.py:186-217 once per pair): ``apap_warp_batch_device`` (grid.z = pair) against the reference's own canvases
+(tests/golden/c5_warp_k*.npz, made by make_golden.py C5warp), against one launch per pair, and against the oracle;
+the separable phases (geometry tables once, per-cell set-up + gather per grid), bands, shared images, the fused stitch.
+Run on the GPU box: ``python -m pytest tests -m gpu``."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import apap_oracle as O
+from cvx_proj_amd.synth import config_pair, synth_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu(native):
+    assert native.lib().apap_device_count() >= 1, "these tests need a GPU; the library found none"
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()
+
+
+def small_batch(n_pairs, seed=50, size=(320, 240), keypoints=90, mesh=9):
+    """Independent pairs that share one geometry (synth_pair's canvas depends on the image size only)."""
+    return [synth_pair(size[0], size[1], keypoints, mesh, seed=seed + k) for k in range(n_pairs)]
+
+
+def test_c5_batched_warp_vs_reference(native, golden):
+    """Config 5 as the metric states it: pairs 0..3 solved in one batched launch and warped in one batched launch.
+    Pairs 0 and 1: canvas SHA-256, every 64th row and the SHA-256 of the in-place inverses equal the REFERENCE's
+    (its pure-Python pixel loop on its own grid); every pair: batched canvas == its own single launch == the oracle
+    on sampled rows."""
+    import torch
+    from cvx_proj_amd.dist import hip_warp_batch, solve_pairs, warp_pairs
+    dev = torch.device("cuda:0")
+    pairs = [config_pair("C5", seed_offset=k) for k in range(4)]
+    grids = solve_pairs(pairs, dev)
+    for k in range(2):
+        assert sha(grids[k]) == golden(f"c5_warp_k{k}")["H_sha256"].tobytes()
+    canv = warp_pairs(pairs, grids, dev)
+    assert sorted(canv) == [0, 1, 2, 3]
+    p0 = pairs[0]
+    for k in range(4):
+        c = canv[k].cpu().numpy()
+        single, hinv = native.local_warp(pairs[k].img, grids[k], p0.mesh[0], p0.mesh[1], p0.final_w, p0.final_h, p0.off_x, p0.off_y)
+        assert np.array_equal(c, single), k
+        rows = list(range(7, p0.final_h, 97))
+        ref = O.local_warp_fast(pairs[k].img, hinv, p0.mesh, (p0.final_w, p0.final_h), (p0.off_x, p0.off_y))
+        assert np.array_equal(c[rows], ref[rows]), k
+        if k < 2:
+            g = golden(f"c5_warp_k{k}")
+            assert tuple(int(v) for v in g["final"]) == (p0.final_w, p0.final_h, p0.off_x, p0.off_y)
+            assert np.array_equal(c[::int(g["warp_rows_every"])], g["warped_rows"])
+            assert sha(c) == g["warped_sha256"].tobytes()
+            assert sha(hinv) == g["Hinv_sha256"].tobytes()
+    assert not np.array_equal(canv[0].cpu().numpy(), canv[1].cpu().numpy())
+    # the inverses the batch entry point writes back (what the reference leaves in its argument), all pairs at once
+    H = torch.stack([torch.from_numpy(g.reshape(-1, 9)) for g in grids]).to(dev)
+    imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)
+    mw, mh = torch.from_numpy(p0.mesh[0].copy()).to(dev), torch.from_numpy(p0.mesh[1].copy()).to(dev)
+    hinv_out = torch.zeros_like(H)
+    out, st = hip_warp_batch(imgs, H, mw, mh, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (100, 100), hinv_out=hinv_out)
+    assert int(st.cpu()[0]) == 0
+    for k in range(2):
+        assert sha(hinv_out[k].cpu().numpy().reshape(100, 100, 3, 3)) == golden(f"c5_warp_k{k}")["Hinv_sha256"].tobytes()
+        assert torch.equal(out[k], canv[k])
+
+
+@pytest.mark.parametrize("rows_per_wave,fast", [(4, 1), (2, 1), (8, 1), (4, 0), (0, 1)])
+def test_batched_warp_equals_per_pair_launches(native, rows_per_wave, fast):
+    """Every kernel form (float32-estimate strips, all-float64 strips, flat order) with grid.z = pair: the canvases
+    and the inverses of a batch equal one call per pair, which equal the oracle."""
+    import torch
+    from cvx_proj_amd.dist import hip_warp_batch
+    dev = torch.device("cuda:0")
+    pairs = small_batch(5)
+    p0 = pairs[0]
+    rows, cols = p0.vertices.shape[:2]
+    ctx = native.Context(warp_rows=rows_per_wave, warp_fast=fast)
+    try:
+        grids = [native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)[0] for p in pairs]
+        H = torch.stack([torch.from_numpy(g.reshape(-1, 9)) for g in grids]).to(dev)
+        imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)
+        mw, mh = torch.from_numpy(p0.mesh[0].copy()).to(dev), torch.from_numpy(p0.mesh[1].copy()).to(dev)
+        hinv_out = torch.zeros_like(H)
+        out, st = hip_warp_batch(imgs, H, mw, mh, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols), ctx=ctx, hinv_out=hinv_out)
+        assert int(st.cpu()[0]) == 0
+        for k, p in enumerate(pairs):
+            single, hinv = native.local_warp(p.img, grids[k], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=ctx)
+            assert np.array_equal(out[k].cpu().numpy(), single), k
+            assert np.array_equal(hinv_out[k].cpu().numpy().reshape(rows, cols, 3, 3), hinv), k
+            ref = O.local_warp_fast(p.img, O.invert_cells_f32(grids[k]), p.mesh, (p.final_w, p.final_h), (p.off_x, p.off_y))
+            assert np.array_equal(single, ref), k
+    finally:
+        ctx.close()
+
+
+def test_phases_geometry_once_then_cells_and_gather(native):
+    """APAP_WARP_GEOMETRY once on a workspace, then APAP_WARP_CELLS | APAP_WARP_GATHER per grid: the same canvases as
+    the one-call form; GATHER alone re-uses everything (same canvas again); a band of every canvas; one image shared
+    by all pairs (stride 0)."""
+    import torch
+    from cvx_proj_amd.dist import hip_warp_batch
+    dev = torch.device("cuda:0")
+    pairs = small_batch(3, seed=70)
+    p0 = pairs[0]
+    rows, cols = p0.vertices.shape[:2]
+    grids = [native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)[0] for p in pairs]
+    H = torch.stack([torch.from_numpy(g.reshape(-1, 9)) for g in grids]).to(dev)
+    imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)
+    mw, mh = torch.from_numpy(p0.mesh[0].copy()).to(dev), torch.from_numpy(p0.mesh[1].copy()).to(dev)
+    geo = (p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols))
+    full, _ = hip_warp_batch(imgs, H, mw, mh, *geo)
+    nbytes = native.lib().apap_warp_batch_workspace_bytes(rows, cols, p0.final_w, p0.final_h, 3)
+    work = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    hip_warp_batch(imgs, H, mw, mh, *geo, work=work, status=status, phases=native.WARP_GEOMETRY)
+    a, _ = hip_warp_batch(imgs, H, mw, mh, *geo, work=work, status=status, phases=native.WARP_CELLS | native.WARP_GATHER)
+    assert torch.equal(a, full)
+    # another set of grids on the same geometry: cells + gather again (the tables are untouched)
+    H2 = H.flip(0).contiguous()
+    b, _ = hip_warp_batch(imgs, H2, mw, mh, *geo, work=work, status=status, phases=native.WARP_CELLS | native.WARP_GATHER)
+    b_ref, _ = hip_warp_batch(imgs, H2, mw, mh, *geo)
+    assert torch.equal(b, b_ref) and not torch.equal(b, full)
+    # gather alone: whatever the workspace holds (H2's cells)
+    c, _ = hip_warp_batch(imgs, H2, mw, mh, *geo, work=work, status=status, phases=native.WARP_GATHER)
+    assert torch.equal(c, b)
+    # a band of every canvas
+    band, _ = hip_warp_batch(imgs, H2, mw, mh, *geo, work=work, status=status, phases=native.WARP_GATHER, rows=(37, 101))
+    assert torch.equal(band, b[:, 37:138])
+    # one image for all pairs
+    one, _ = hip_warp_batch(imgs[1], H, mw, mh, *geo)
+    for k in range(3):
+        single, _ = native.local_warp(pairs[1].img, grids[k], p0.mesh[0], p0.mesh[1], p0.final_w, p0.final_h, p0.off_x, p0.off_y)
+        assert np.array_equal(one[k].cpu().numpy(), single)
+    assert int(status.cpu()[0]) == 0
+
+
+def test_batched_stitch_equals_per_pair_stitch(native):
+    import torch
+    from cvx_proj_amd.dist import hip_warp_batch
+    dev = torch.device("cuda:0")
+    pairs = small_batch(3, seed=90)
+    p0 = pairs[0]
+    rows, cols = p0.vertices.shape[:2]
+    rng = np.random.default_rng(5)
+    centers = rng.integers(0, 256, (3,) + p0.shape, dtype=np.uint8)
+    centers[rng.random(centers.shape[:3]) < 0.2] = 0
+    grids = [native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)[0] for p in pairs]
+    H = torch.stack([torch.from_numpy(g.reshape(-1, 9)) for g in grids]).to(dev)
+    imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)
+    mw, mh = torch.from_numpy(p0.mesh[0].copy()).to(dev), torch.from_numpy(p0.mesh[1].copy()).to(dev)
+    geo = (p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols))
+    out, st = hip_warp_batch(imgs, H, mw, mh, *geo, centers=torch.from_numpy(centers).to(dev))
+    shared, _ = hip_warp_batch(imgs, H, mw, mh, *geo, centers=torch.from_numpy(centers[2]).to(dev))
+    assert int(st.cpu()[0]) == 0
+    for k, p in enumerate(pairs):
+        ref, _ = native.local_stitch(p.img, centers[k], grids[k], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+        assert np.array_equal(out[k].cpu().numpy(), ref), k
+        warped, _ = native.local_warp(p.img, grids[k], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+        assert np.array_equal(ref, O.stitch(warped, centers[k], (p.off_x, p.off_y)))
+        ref2, _ = native.local_stitch(p.img, centers[2], grids[k], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+        assert np.array_equal(shared[k].cpu().numpy(), ref2), k
+
+
+def test_batch_argument_checks(native):
+    import torch
+    dev = torch.device("cuda:0")
+    pairs = small_batch(2, seed=95)
+    p0 = pairs[0]
+    rows, cols = p0.vertices.shape[:2]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)    # noqa: E731
+    imgs, H = t(np.stack([p.img for p in pairs])), torch.zeros((2, rows * cols, 9), dtype=torch.float32, device=dev)
+    mw, mh = t(p0.mesh[0]), t(p0.mesh[1])
+    out = torch.zeros((2, p0.final_h, p0.final_w, 3), dtype=torch.uint8, device=dev)
+    nbytes = native.lib().apap_warp_batch_workspace_bytes(rows, cols, p0.final_w, p0.final_h, 2)
+    assert nbytes > native.lib().apap_warp_workspace_bytes(rows, cols, p0.final_w, p0.final_h)
+    work, st = torch.zeros(nbytes, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    L = native.lib()
+
+    def call(batch=2, out_stride=p0.final_h * p0.final_w * 3, phases=native.WARP_ALL, wbytes=nbytes, row_count=p0.final_h):
+        return L.apap_warp_batch_device(None, imgs.data_ptr(), imgs[0].numel(), p0.shape[0], p0.shape[1], None, 0, 0, 0, H.data_ptr(),
+                                        rows, cols, mw.data_ptr(), mw.numel(), mh.data_ptr(), mh.numel(), p0.final_w, p0.final_h,
+                                        p0.off_x, p0.off_y, 0, row_count, out.data_ptr(), out_stride, None, batch, phases,
+                                        work.data_ptr(), wbytes, st.data_ptr(), None)
+    assert call(batch=0) == native.ERR_INVALID_ARG
+    assert call(out_stride=100) == native.ERR_INVALID_ARG           # canvases would overlap
+    assert call(phases=0) == native.ERR_INVALID_ARG and call(phases=8) == native.ERR_INVALID_ARG
+    assert call(wbytes=nbytes - 256) == native.ERR_WORKSPACE
+    assert call(row_count=p0.final_h + 1) == native.ERR_INVALID_ARG
+    # an all-zero grid is singular in every cell: the status word says so, like numpy.linalg.inv would raise (apap.py:203)
+    assert call() == native.OK
+    torch.cuda.synchronize()
+    assert int(st.cpu()[0]) & 1
