@@ -99,22 +99,50 @@ class Resident:
         self.wwork_bytes = N.lib().apap_warp_workspace_bytes(self.rows, self.cols, pair.final_w, pair.final_h)
         self.wwork = torch.empty(self.wwork_bytes, dtype=torch.uint8, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the resident pipeline's form of the step (one pair per launch): the canvas row / column tables of this geometry are
+        # built once (here), the solve's tail leaves every cell warp ready in `pwork`, the warp step is the gather kernel alone
+        self.resident = batch == 1
+        self.pwork = torch.zeros(self.wwork_bytes, dtype=torch.uint8, device=dev)
+        self._warp_phases(torch.cuda.current_stream().cuda_stream, N.WARP_GEOMETRY, self.pwork)
 
-    def solve(self, stream):
+    def _warp_phases(self, stream, phases, work, img=None, out=None):
+        p = self.pair
+        img = self.img if img is None else img
+        out = self.out if out is None else out
+        N.check(N.lib().apap_warp_batch_device(self.ctx, img.data_ptr(), 0, p.shape[0], p.shape[1], None, 0, 0, 0, self.H.data_ptr(),
+                                               self.rows, self.cols, self.mesh_w.data_ptr(), p.mesh.shape[1], self.mesh_h.data_ptr(),
+                                               p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y, 0, p.final_h, out.data_ptr(), 0,
+                                               None, 1, phases, work.data_ptr(), self.wwork_bytes, self.status.data_ptr(),
+                                               ctypes.c_void_p(stream)))
+
+    def solve_plain(self, stream):
+        """The solve alone (H grid only): what a caller that does not warp on this GPU runs."""
         p = self.pair
         N.check(N.lib().apap_solve_batch_device(self.ctx, self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, self.cells,
                                                 p.gamma, p.sigma, self.den.data_ptr(), self.H.data_ptr(), self.batch,
                                                 self.work.data_ptr(), self.work_bytes, ctypes.c_void_p(stream)))
 
-    def warp(self, stream, img=None, out=None):
+    def solve(self, stream):
+        """The solve of the resident pipeline: H grid + every cell warp ready (apap_solve_warp_batch_device)."""
+        if not self.resident:
+            return self.solve_plain(stream)
         p = self.pair
-        img = self.img if img is None else img
-        out = self.out if out is None else out
-        N.check(N.lib().apap_warp_device(self.ctx, img.data_ptr(), p.shape[0], p.shape[1], self.H.data_ptr(), self.rows,
-                                         self.cols, self.mesh_w.data_ptr(), p.mesh.shape[1], self.mesh_h.data_ptr(),
-                                         p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
-                                         out.data_ptr(), None, self.wwork.data_ptr(), self.wwork_bytes,
-                                         self.status.data_ptr(), ctypes.c_void_p(stream)))
+        N.check(N.lib().apap_solve_warp_batch_device(self.ctx, self.table.data_ptr(), self.n, self.vert.data_ptr(), 0, p.gamma, p.sigma,
+                                                     self.den.data_ptr(), self.H.data_ptr(), 1, self.work.data_ptr(), self.work_bytes,
+                                                     self.rows, self.cols, self.mesh_w.data_ptr(), p.mesh.shape[1],
+                                                     self.mesh_h.data_ptr(), p.mesh.shape[1], p.final_w, p.final_h, p.off_x, p.off_y,
+                                                     self.pwork.data_ptr(), self.wwork_bytes, self.status.data_ptr(),
+                                                     ctypes.c_void_p(stream)))
+
+    def warp(self, stream, img=None, out=None):
+        """The warp step of the resident pipeline: the gather kernel on the tables the solve left (no set-up launch)."""
+        if not self.resident:
+            return self.warp_standalone(stream, img, out)
+        self._warp_phases(stream, N.WARP_GATHER, self.pwork, img, out)
+
+    def warp_standalone(self, stream, img=None, out=None):
+        """apap_warp_device on a grid from anywhere: set-up launch (inverses, records, lookup tables) + gather."""
+        self._warp_phases(stream, N.WARP_ALL, self.wwork, img, out)
 
     def second_lane(self):
         """A second canvas, workspace and status word on a stream of its own: the same pair warped twice at once
@@ -507,6 +535,10 @@ def main():
     ap.add_argument("--want-waves", type=int, help="tuning: APAP_OPT_WANT_WAVES of the context (K1 keypoint splits)")
     ap.add_argument("--warp-rows", type=int, choices=[0, 2, 4, 8], help="tuning: APAP_OPT_WARP_ROWS (0 = flat-order warp kernel)")
     ap.add_argument("--warp-fast", type=int, choices=[0, 1], help="tuning: APAP_OPT_WARP_FAST (0 = float64 for every pixel of K3)")
+    ap.add_argument("--warp-walk", type=int, choices=[0, 1], help="K3 form: 1 = persistent column-walk kernel, 0 = one strip per wave")
+    ap.add_argument("--warp-waves", type=int, help="tuning, walk form: resident waves per CU")
+    ap.add_argument("--warp-stage", type=int, choices=[1, 2], help="tuning, walk form: rows per pipeline stage")
+    ap.add_argument("--warp-min-run", type=int, help="tuning, walk form: least rows per wave on small canvases")
     ap.add_argument("--fused-max-cells", type=int, help="tuning: APAP_OPT_FUSED_MAX_CELLS (fused K1 + K2 launch for small meshes)")
     ap.add_argument("--cold-mb", type=float, default=640.0,
                     help="cold-cache warp leg: rotate over this many MB of (image, canvas) copies (0 = skip)")
@@ -567,6 +599,9 @@ def main():
         ctx.set("fused_max_cells", a.fused_max_cells)
     if a.warp_fast is not None:
         ctx.set("warp_fast", a.warp_fast)
+    for name in ("warp_walk", "warp_waves", "warp_stage", "warp_min_run"):
+        if getattr(a, name) is not None:
+            ctx.set(name, getattr(a, name))
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -631,6 +666,16 @@ def main():
     t_solve = timed(run_solve, a.steps)
     t_warp = timed(run_warp, a.steps)
     assert int(res.status.cpu()[0]) == 0, "device status word set during the timed region"
+    canvas_resident = res.out.clone()
+    # the same two halves as separate services: the solve alone, and the warp of a grid from anywhere (its own set-up launch)
+    for _ in range(a.warmup):
+        res.solve_plain(stream)
+        res.warp_standalone(stream)
+    t_solve_plain = timed(lambda: res.solve_plain(stream), a.steps)
+    t_warp_alone = timed(lambda: res.warp_standalone(stream), a.steps)
+    assert torch.equal(res.out, canvas_resident), "stand-alone warp and resident warp step disagree"
+    del canvas_resident
+    res.solve(stream)       # leave the resident tables in place for what follows
 
     def extra(fn):      # rank-local extras, not part of `value`
         fn(stream)
@@ -663,7 +708,7 @@ def main():
     torch.cuda.synchronize()
 
     def warp_pair_of_lanes():
-        res.warp(stream)
+        res.warp_standalone(stream)
         res.warp_lane2()
     for _ in range(a.warmup):
         warp_pair_of_lanes()
@@ -686,6 +731,11 @@ def main():
         res.ransac(stream)
     torch.cuda.synchronize()
     kern = read_kernel_ms(ctx)
+    for _ in range(a.steps):            # the set-up launch of the stand-alone warp (the resident step has none)
+        res.warp_standalone(stream)
+    torch.cuda.synchronize()
+    kern["invert"] = read_kernel_ms(ctx)["invert"]
+    res.solve(stream)
     kern_cold = None
     if cold:
         for _ in range(max(a.steps, len(cold))):
@@ -693,6 +743,27 @@ def main():
         torch.cuda.synchronize()
         kern_cold = read_kernel_ms(ctx)
     ctx.set("profile", 0)
+
+    def back_to_back(fn, n):
+        """Average duration of n launches of one kernel issued back to back, between two HIP events on the launch stream: the
+        kernel's duration plus the ~1 us gap between dependent launches - what rocprofv3's per-kernel average agrees with.  (A
+        pair of events around EVERY launch, the context's profiling slots, adds ~2 us of event handling to each launch: 13 % of a
+        15 us kernel, nothing next to K1's 150 us.)"""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    condition(lambda: res.warp(stream))
+    k3_warm_ms = back_to_back(lambda: res.warp(stream), max(a.steps, 20))
+    k3_cold_ms = None
+    if cold:
+        for _ in range(len(cold)):
+            warp_cold()
+        k3_cold_ms = back_to_back(warp_cold, max(a.steps, len(cold)))
 
     # a caller's FIRST solve from an idle chip (clocks down): one call, bracketed by synchronisation
     from_idle = []
@@ -849,6 +920,7 @@ def main():
             traffic = tj.get(f"{a.config}:k_assemble_{resolved}")
             traffic_warp = tj.get(f"{a.config}:k_warp_fast", tj.get(f"{a.config}:k_warp_rows"))
         # K3 (HBM-bound half of the metric): 6 B per in-range pixel, 3 B per blank one
+        k3_name = "k_warp_walk" if ctx.get("warp_walk") else "k_warp_fast"
         out_pixels = pair.final_w * pair.final_h
         nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu())
         warp_bytes = 6 * nz + 3 * (out_pixels - nz)
@@ -872,6 +944,15 @@ def main():
             "warp": {"value": units_warp * a.steps / t_warp / 1e6, "unit": "Mpix/s",
                      "ms_per_step": t_warp / a.steps * 1e3},
             "solve_ms_per_step": t_solve / a.steps * 1e3,
+            "step_form": ("resident pipeline: canvas row / column tables built once per geometry, the eigen-solve kernel's tail leaves "
+                          "every cell warp ready (apap_solve_warp_batch_device), the warp step is the gather kernel alone "
+                          "(apap_warp_batch_device, APAP_WARP_GATHER); the per-cell set-up is inside solve_ms_per_step") if res.resident
+                         else "solve and stand-alone warp (a batch of pairs per solve launch)",
+            "standalone": {"solve_ms_per_step": t_solve_plain / a.steps * 1e3, "value": units_solve * a.steps / t_solve_plain,
+                           "warp_ms_per_step": t_warp_alone / a.steps * 1e3,
+                           "warp_value": units_warp * a.steps / t_warp_alone / 1e6, "warp_unit": "Mpix/s",
+                           "note": "the two halves as separate services: apap_solve_device (H grid only) and apap_warp_device on a "
+                                   "grid from anywhere (its own set-up launch: inverses, records, lookup tables, then the gather)"},
             "warp_two_in_flight": {"value": 2 * units_warp * a.steps / t_warp2 / 1e6, "unit": "Mpix/s",
                                    "ms_per_pair": t_warp2 / a.steps / 2 * 1e3,
                                    "note": "the same warp step issued twice per step on two streams into two canvases: one warp "
@@ -914,8 +995,10 @@ def main():
                                  "the algorithmic count prices at 58 flops; the kernel runs ~266 issue cycles per 64 "
                                  "pairs whatever the MFMA shape (profiles/r02_k1_variants.txt, DESIGN.md section 3)"},
             "roofline_warp": {
-                "kernel": "k_warp_fast", "cache": "warm", "bound": "hbm", "achieved": warp_bytes / (kern["warp"] * 1e-3) / 1e9,
-                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (kern["warp"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "kernel": k3_name, "cache": "warm", "bound": "hbm", "achieved": warp_bytes / (k3_warm_ms * 1e-3) / 1e9,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (k3_warm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "kernel_ms": k3_warm_ms, "kernel_ms_with_an_event_pair_per_launch": kern["warp"],
+                "timing": "HIP events on the launch stream around a run of launches issued back to back (duration + launch gap)",
                 "traffic": traffic_warp,
                 "note": "the bench warps the same 25 MB image into the same 27 MB canvas back to back: both stay in the "
                         "256 MiB Infinity Cache, so this figure is priced against a memory the kernel mostly does not "
@@ -930,9 +1013,10 @@ def main():
                                  "ms_per_step": t_warp_cold / a.steps * 1e3, "buffer_sets": len(cold),
                                  "bytes_rotated": len(cold) * (res.img.numel() + res.out.numel())}
             line["roofline_warp_cold"] = {
-                "kernel": "k_warp_fast", "cache": "cold", "bound": "hbm",
-                "achieved": warp_bytes / (kern_cold["warp"] * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": warp_bytes / (kern_cold["warp"] * 1e-3) / 1e9 / PEAK_HBM_GBS, "kernel_ms": kern_cold["warp"],
+                "kernel": k3_name, "cache": "cold", "bound": "hbm",
+                "achieved": warp_bytes / (k3_cold_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": warp_bytes / (k3_cold_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "kernel_ms": k3_cold_ms,
+                "kernel_ms_with_an_event_pair_per_launch": kern_cold["warp"],
                 "traffic": tj.get(f"{a.config}:k_warp_fast:cold"),
                 "note": f"{len(cold)} (image, canvas) sets = {len(cold) * (res.img.numel() + res.out.numel()) / 1e6:.0f} MB "
                         f"warped in rotation: every launch reads its source from HBM and writes a canvas that is not cached"}

@@ -28,7 +28,8 @@ VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1,
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 # options of a context (include/apap_hip.h)
 OPT_SOLVER_VARIANT, OPT_EIGEN_SOLVER, OPT_CAREFUL, OPT_PROFILE, OPT_WANT_WAVES, OPT_WARP_ROWS, OPT_WEIGHT_CHUNK_KB, \
-    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS = range(11)
+    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS, OPT_WARP_WALK, OPT_WARP_WAVES, OPT_WARP_STAGE, \
+    OPT_WARP_MIN_RUN = range(15)
 
 
 class ApapError(RuntimeError):
@@ -101,6 +102,9 @@ SIGNATURES = {
     "apap_solve_batch_workspace_bytes": (C.c_size_t, [_vp, C.c_int, C.c_int, C.c_int]),
     "apap_solve_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_longlong, C.c_int, C.c_double, C.c_double, _vp, _vp,
                                           C.c_int, _vp, C.c_size_t, _vp]),
+    "apap_solve_warp_batch_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_longlong, C.c_double, C.c_double, _vp, _vp, C.c_int, _vp,
+                                               C.c_size_t, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, _vp, C.c_size_t, _vp, _vp]),
     "apap_weights_device": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_double, _vp, _vp]),
     "apap_warp_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apap_warp_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int,
@@ -185,7 +189,8 @@ class Context:
     _NAMES = {"variant": OPT_SOLVER_VARIANT, "eigen": OPT_EIGEN_SOLVER, "careful": OPT_CAREFUL, "profile": OPT_PROFILE,
               "want_waves": OPT_WANT_WAVES, "warp_rows": OPT_WARP_ROWS, "weight_chunk_kb": OPT_WEIGHT_CHUNK_KB,
               "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST, "overlap_pcie": OPT_OVERLAP_PCIE,
-              "plan_cells": OPT_PLAN_CELLS}
+              "plan_cells": OPT_PLAN_CELLS, "warp_walk": OPT_WARP_WALK, "warp_waves": OPT_WARP_WAVES, "warp_stage": OPT_WARP_STAGE,
+              "warp_min_run": OPT_WARP_MIN_RUN}
 
     def set(self, name, value):
         check(lib().apap_ctx_set_option(self._h, self._NAMES[name], int(value)))

@@ -1099,13 +1099,26 @@ __device__ __forceinline__ void qr_resolve(const double *__restrict__ table, int
     }
 }
 
+// What the solve's tail needs to leave a cell "warp ready": where the warp's per-cell tables of this pair live and the
+// geometry the float32 estimate's anchors come from.  hinv_pad == nullptr: the solve writes H only.
+struct WarpEmit {
+    double *hinv_pad;       // pair 0's tables (apap_warp_batch_device's workspace); pair k at + k * stride
+    float4 *frec, *fexact;
+    long long hinv_stride, frec_stride;
+    const double *mesh_w, *mesh_h;
+    int n_w, n_h, mesh_rows, mesh_cols, final_w, final_h, off_x, off_y;
+    int *status;
+};
+__device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, const float (&Hf)[9]);
+
 // The per-cell tail shared by K2 and the fused small-mesh kernel: from the 30 moment sums of a
 // cell to its float32 homography.  Lanes = cells; inactive lanes are simply not in the wave votes.
 template <bool kUseInverseIteration>
 __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], const double *__restrict__ denorm,
                                                   int pick_rank, int careful, const double *__restrict__ table, int n,
                                                   double vx, double vy, double gamma, double inv_sigma,
-                                                  float *__restrict__ out /* 9 floats, or nullptr */) {
+                                                  float *__restrict__ out /* 9 floats, or nullptr */,
+                                                  const WarpEmit &we, int pair, int cell) {
     // A^T W^2 A = [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]  (3x3 blocks)
     double a[45];
 #pragma unroll
@@ -1190,8 +1203,12 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
 #pragma unroll
             for (int k = 0; k < 9; ++k) q[k] = plain ? q[k] : t2[k] / t2[8];
         }
+        float hf[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) out[k] = (float)q[k];
+        for (int k = 0; k < 9; ++k) out[k] = hf[k] = (float)q[k];
+        // the caller warps next: the cell's inverse, its float32-estimate record and exact-path floats, straight into the
+        // warp's workspace (what k_warp_setup's per-cell half would compute from the stored grid: the same function)
+        if (we.hinv_pad) warp_emit_from_solve(we, pair, cell, hf);
     }
 #ifdef APAP_TRACE_SMALL
     APAP_STAMP(4);
@@ -1212,7 +1229,7 @@ __global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const do
                                                      float *__restrict__ H, BatchStride bs,
                                                      const double *__restrict__ table, int n,
                                                      const double *__restrict__ vertices, double gamma,
-                                                     double inv_sigma, int careful) {
+                                                     double inv_sigma, int careful, const WarpEmit we) {
     moments += (long long)blockIdx.z * bs.moments;
     denorm += (long long)blockIdx.z * bs.denorm;
     H += (long long)blockIdx.z * bs.H;
@@ -1229,7 +1246,7 @@ __global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const do
         for (int j = 0; j < kMoments; ++j) m[j] += slab[(size_t)j * cells_pad];
     }
     eigen_denorm_cell<kUseInverseIteration>(m, denorm, pick_rank, careful, table, n, vertices[2 * cc], vertices[2 * cc + 1],
-                                            gamma, inv_sigma, cell < cells ? H + (size_t)cell * 9 : nullptr);
+                                            gamma, inv_sigma, cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell);
 }
 
 // --------------------------------------------------------------------------------
@@ -1251,7 +1268,7 @@ template <bool kUseInverseIteration>
 __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__restrict__ table, int n,
                                                      const double *__restrict__ vertices, int cells, double gamma,
                                                      double inv_sigma, const double *__restrict__ denorm, int pick_rank,
-                                                     int careful, float *__restrict__ H, BatchStride bs) {
+                                                     int careful, float *__restrict__ H, BatchStride bs, const WarpEmit we) {
     // The block is alone on its CU (the K2 tail's registers) and its waves take only 4 steps of a
     // chunk each, far too little work to hide the next chunk's global load behind: kRing chunks are
     // fetched per round with their loads all in flight together (C1's 150 keypoints: one round, one
@@ -1401,7 +1418,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
 #pragma unroll
     for (int j = 0; j < kMoments; ++j) m[j] = tot[lane * kRow + j];
     eigen_denorm_cell<kUseInverseIteration>(m, s_denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
-                                            cell < cells ? H + (size_t)cell * 9 : nullptr);
+                                            cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell);
 #ifdef APAP_TRACE_SMALL
     tr[4] = clock64();
     if (blockIdx.x == 3 && tid == 0)
@@ -1648,7 +1665,10 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
 // the offsets only and is SHARED by all pairs of a batch,
 //   lut [final_h + final_w] i32 | fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
 // then, per pair of the batch, what depends on that pair's H grid,
-//   hinv_pad [cells][10] f64 | frec [(rows + 1)(cols + 1)][3] float4
+//   hinv_pad [cells][10] f64 | frec [(rows + 1)(cols + 1)][3] float4 | fexact [(rows + 1)(cols + 1)][3] float4
+// fexact (column-walk kernel): the cell's stored float32 inverse as it is - 9 floats, then 1.0f when they ARE the inverse the
+// exact path must use (a float32 grid's ordinary cell), 0 otherwise (a float64 grid, the extra row / column) - so that a
+// pixel in doubt is settled from registers instead of through a dependent load of hinv_pad.
 // frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
 // `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row,
 // float bits of dy}, dx / dy = signed distance from the cell's anchor (its middle pixel); pixels that are not
@@ -1657,6 +1677,7 @@ struct WarpWork {
     double *hinv_pad;   // pair 0; pair k at + k * hinv_stride doubles
     int *lut;
     float4 *frec;       // pair 0; pair k at + k * frec_stride float4
+    float4 *fexact;     // pair 0; same stride as frec
     unsigned *fcol;
     uint2 *frow;
     int *src_rows;      // [rows][2] source-row interval per cell row, then 1 flag word (bit 0: irregular mesh)
@@ -1687,11 +1708,78 @@ inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int f
     const size_t frec_bytes = round256(((size_t)mesh_rows + 1) * ((size_t)mesh_cols + 1) * 3 * sizeof(float4));
     w.hinv_pad = (double *)p;
     w.frec = (float4 *)(p + hinv_bytes);
-    w.hinv_stride = (long long)((hinv_bytes + frec_bytes) / sizeof(double));
-    w.frec_stride = (long long)((hinv_bytes + frec_bytes) / sizeof(float4));
-    p += (hinv_bytes + frec_bytes) * (size_t)(batch < 1 ? 1 : batch);
+    w.fexact = (float4 *)(p + hinv_bytes + frec_bytes);
+    w.hinv_stride = (long long)((hinv_bytes + 2 * frec_bytes) / sizeof(double));
+    w.frec_stride = (long long)((hinv_bytes + 2 * frec_bytes) / sizeof(float4));
+    p += (hinv_bytes + 2 * frec_bytes) * (size_t)(batch < 1 ? 1 : batch);
     w.bytes = (size_t)(p - (char *)base);
     return w;
+}
+
+// entry `e` of the extra row / column of the record tables: everything in doubt, no exact floats
+__device__ __forceinline__ void warp_extra_entry(float4 *__restrict__ frec, float4 *__restrict__ fexact, size_t e) {
+    const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fast_record(z, false, 0.0, 0.0, 1.0, 1.0, frec + e * 3);
+    fexact[e * 3] = fexact[e * 3 + 1] = fexact[e * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// The warp's per-cell tables of mesh cell (er, ec) from its FORWARD matrix `m` (the grid's values, widened): the inverse in
+// the grid's dtype T (apap.py:201-203), padded for the exact path, its float32-estimate record, its exact-path floats.  One
+// function for k_warp_setup (the stored grid) and for the solve's tail (the value it has just rounded to float32).
+template <typename T>
+__device__ __forceinline__ void warp_cell_tables(const double (&m)[9], int er, int ec, int mesh_cols, const double *__restrict__ mesh_w,
+                                                 int n_w, const double *__restrict__ mesh_h, int n_h, int final_w, int final_h,
+                                                 int off_x, int off_y, double *__restrict__ hinv_pad, T *__restrict__ hinv_dense,
+                                                 float4 *__restrict__ frec, float4 *__restrict__ fexact, int *status, int *src_rows) {
+    const int cell = er * mesh_cols + ec;
+    const size_t e = (size_t)er * (mesh_cols + 1) + ec;
+    double r[9];
+    int x0, y0, sx, sy;      // the edge loads travel with the matrix loads
+    const bool okx = fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
+    const bool oky = fast_origin(mesh_h, n_h, er, final_h, y0, sy);
+    if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
+    double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
+    // the inverse rounded to the grid's dtype (what the reference stores back, apap.py:203),
+    // widened once here instead of nine v_cvt_f64_f32 per pixel in the warp kernel
+    double hd[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) hd[k] = (double)(T)r[k];
+    p[0] = make_double2(hd[0], hd[1]);
+    p[1] = make_double2(hd[2], hd[3]);
+    p[2] = make_double2(hd[4], hd[5]);
+    p[3] = make_double2(hd[6], hd[7]);
+    p[4] = make_double2(hd[8], 0.0);
+    if (hinv_dense) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
+    }
+    {   // the stored inverse itself, for the column-walk kernel's exact path (float32 grids: the floats ARE the inverse)
+        const float valid = sizeof(T) == sizeof(float) ? 1.0f : 0.0f;
+        fexact[e * 3] = make_float4((float)hd[0], (float)hd[1], (float)hd[2], (float)hd[3]);
+        fexact[e * 3 + 1] = make_float4((float)hd[4], (float)hd[5], (float)hd[6], (float)hd[7]);
+        fexact[e * 3 + 2] = make_float4((float)hd[8], valid, 0.f, 0.f);
+    }
+    // anchor in the middle of the cell: the estimate's error grows with the distance from it
+    fast_record(hd, okx && oky, (double)(x0 + sx / 2 - off_x), (double)(y0 + sy / 2 - off_y), (double)(sx - sx / 2),
+                (double)(sy - sy / 2), frec + e * 3, src_rows ? src_rows + 2 * er : nullptr);
+}
+
+// the solve's tail (eigen_denorm_cell) leaves its cell warp ready; the last column / row also write the extra entries
+__device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, const float (&Hf)[9]) {
+    double m[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = (double)Hf[k];
+    const int er = cell / we.mesh_cols, ec = cell - er * we.mesh_cols;
+    double *hinv_pad = we.hinv_pad + (long long)pair * we.hinv_stride;
+    float4 *frec = we.frec + (long long)pair * we.frec_stride, *fexact = we.fexact + (long long)pair * we.frec_stride;
+    warp_cell_tables<float>(m, er, ec, we.mesh_cols, we.mesh_w, we.n_w, we.mesh_h, we.n_h, we.final_w, we.final_h, we.off_x, we.off_y,
+                            hinv_pad, (float *)nullptr, frec, fexact, we.status, (int *)nullptr);
+    const size_t stride = (size_t)we.mesh_cols + 1;
+    if (ec == we.mesh_cols - 1) warp_extra_entry(frec, fexact, (size_t)er * stride + we.mesh_cols);
+    if (er == we.mesh_rows - 1) {
+        warp_extra_entry(frec, fexact, (size_t)we.mesh_rows * stride + ec);
+        if (ec == we.mesh_cols - 1) warp_extra_entry(frec, fexact, (size_t)we.mesh_rows * stride + we.mesh_cols);
+    }
 }
 
 template <typename T>
@@ -1704,7 +1792,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
                                                     int *__restrict__ lut, int *status, int off_x, int off_y,
                                                     float4 *__restrict__ frec, unsigned *__restrict__ fcol,
                                                     uint2 *__restrict__ frow, int *__restrict__ src_rows,
-                                                    long long hinv_stride, long long frec_stride) {
+                                                    long long hinv_stride, long long frec_stride, float4 *__restrict__ fexact) {
     // grid.y = pair of a batch (every pair has the same mesh and canvas: the lookup tables are built once, by
     // y = 0); blocks [0, inv_blocks) are the per-cell half - what depends on the H grid -, the rest the tables.
     // Either half may be absent from a launch (inv_blocks = 0, or a grid of inv_blocks blocks).
@@ -1722,41 +1810,21 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         H += pair * (size_t)cells * 9;
         hinv_pad += pair * hinv_stride;
         frec += pair * frec_stride;
+        fexact += pair * frec_stride;
         if (hinv_dense) hinv_dense += pair * (size_t)cells * 9;
         const int e = blockIdx.x * 256 + tid;
         const int er = e / (mesh_cols + 1), ec = e - er * (mesh_cols + 1);
         if (er > mesh_rows) return;
         if (er == mesh_rows || ec == mesh_cols) {
-            const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            fast_record(z, false, 0.0, 0.0, 1.0, 1.0, frec + (size_t)e * 3);
+            warp_extra_entry(frec, fexact, e);
             return;
         }
         const int cell = er * mesh_cols + ec;
-        double m[9], r[9];
+        double m[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
-        int x0, y0, sx, sy;      // the edge loads travel with the matrix loads
-        const bool okx = fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
-        const bool oky = fast_origin(mesh_h, n_h, er, final_h, y0, sy);
-        if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
-        double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
-        // the inverse rounded to the grid's dtype (what the reference stores back, apap.py:203),
-        // widened once here instead of nine v_cvt_f64_f32 per pixel in the warp kernel
-        double hd[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) hd[k] = (double)(T)r[k];
-        p[0] = make_double2(hd[0], hd[1]);
-        p[1] = make_double2(hd[2], hd[3]);
-        p[2] = make_double2(hd[4], hd[5]);
-        p[3] = make_double2(hd[6], hd[7]);
-        p[4] = make_double2(hd[8], 0.0);
-        if (hinv_dense) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
-        }
-        // anchor in the middle of the cell: the estimate's error grows with the distance from it
-        fast_record(hd, okx && oky, (double)(x0 + sx / 2 - off_x), (double)(y0 + sy / 2 - off_y), (double)(sx - sx / 2),
-                    (double)(sy - sy / 2), frec + (size_t)e * 3, src_rows ? src_rows + 2 * er : nullptr);
+        warp_cell_tables<T>(m, er, ec, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h, off_x, off_y, hinv_pad, hinv_dense,
+                            frec, fexact, status, src_rows);
         return;
     }
     if (blockIdx.y != 0) return;
@@ -2379,6 +2447,340 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     }
 }
 
+// K3, persistent column-walk form (round 4).  The strip kernel above gives every wave ONE strip and a chain of three
+// dependent memory round trips (column table -> cell records -> source pixels) before its stores; 9024 such waves on 6144
+// slots are 1.45 generations that compute together and then wait together (profiles/r03_k3_experiments.txt).  Here the grid
+// is sized to the chip (`waves_per_cu` resident waves on every CU, dynamic LDS caps the blocks per CU), the canvas
+// (all canvases of a batch) is cut into `wave-rows` - 256 pixels of one canvas row - in the order (pair, column block, row), and
+// every wave takes one CONTIGUOUS share of them: it walks DOWN a column block.  What that buys:
+//   * the column entries are loaded and unpacked once per wave, the cell records once per cell row the walk enters (every
+//     ~11 rows at C3) instead of once or twice per 4-row strip;
+//   * the walk is software-pipelined in stages of S rows: the gathers of stage i are in flight while stage i + 1's offsets are
+//     computed, and are waited for (counted vmcnt) only when stage i + 1's own gathers have been issued; the row entries of
+//     the next stage are prefetched by scalar loads;
+//   * no generations: every wave does the same amount of work (+- one wave-row), all start and end together.
+// Source pixels come through a buffer descriptor over the image: the hardware's range check returns 0 for the "outside"
+// marker 0xffffffff, so a gathered dword needs one AND instead of clamp / shift / sign mask; the image's very last pixel
+// (whose dword would reach one byte past the image) is taken out of the common path: it goes through the doubt loop and is
+// patched from a value read once per wave.  Per-pixel arithmetic, doubt rule and exact path are those of k_warp_fast.
+struct WalkGeo {
+    WarpStrides st;
+    int img_h, img_w, mesh_rows, mesh_cols, final_w, final_h, off_x, off_y, center_h, center_w, row_begin, row_count;
+    unsigned nbx;        // column blocks of 256 pixels per canvas row
+    unsigned per, rem;   // wave-rows per wave: every wave takes `per`, the first `rem` waves one more
+};
+
+struct FastConst {      // per lane: what k_warp_fast keeps per pixel while it stays in one cell row
+    float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
+    int n0x[4], n0y[4];
+    unsigned thr[4];
+    float ea[10], eb[10];   // the stored inverses of the first and the last pixel's cells (fexact: 9 floats + valid flag)
+};
+
+__device__ __forceinline__ void load_fast_const(FastConst &c, const float4 *__restrict__ frec, const float4 *__restrict__ fexact,
+                                                unsigned base, const unsigned (&col)[4], const float (&dxf)[4]) {
+    const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
+    const float4 *xa = fexact + (size_t)(base + col[0]) * 3, *xb = fexact + (size_t)(base + col[3]) * 3;
+    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+    {
+        const float4 u0 = xa[0], u1 = xa[1], u2 = xa[2], w0 = xb[0], w1 = xb[1], w2 = xb[2];
+        c.ea[0] = u0.x; c.ea[1] = u0.y; c.ea[2] = u0.z; c.ea[3] = u0.w; c.ea[4] = u1.x; c.ea[5] = u1.y; c.ea[6] = u1.z; c.ea[7] = u1.w;
+        c.ea[8] = u2.x; c.ea[9] = u2.y;
+        c.eb[0] = w0.x; c.eb[1] = w0.y; c.eb[2] = w0.z; c.eb[3] = w0.w; c.eb[4] = w1.x; c.eb[5] = w1.y; c.eb[6] = w1.z; c.eb[7] = w1.w;
+        c.eb[8] = w2.x; c.eb[9] = w2.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool is_a = (k == 0) || (k != 3 && col[k] == col[0]);
+        const float4 q0 = is_a ? a0 : b0, q1 = is_a ? a1 : b1, q2 = is_a ? a2 : b2;
+        c.nx0[k] = __builtin_fmaf(q0.x, dxf[k], q0.z);
+        c.ny0[k] = __builtin_fmaf(q0.w, dxf[k], q1.y);
+        c.dn0[k] = __builtin_fmaf(q1.w, dxf[k], q1.z);
+        c.bx[k] = q0.y; c.by[k] = q1.x; c.h7[k] = q2.x;
+        c.n0x[k] = __float_as_int(q2.y); c.n0y[k] = __float_as_int(q2.z);
+        c.thr[k] = __float_as_uint(q2.w);
+        // a third cell inside four pixels (cells narrower than the group): exact path
+        if (k == 1 || k == 2) c.thr[k] = (!is_a && col[k] != col[3]) ? 0xffffffffu : c.thr[k];
+    }
+}
+
+template <bool kBlend>
+__device__ __forceinline__ void walk_store_row(const WalkGeo &a, const uint8_t *__restrict__ center, uint8_t *__restrict__ out,
+                                               unsigned (&px)[4], int y, int j0, int npx, unsigned clast) {
+    if (kBlend) {
+        const int ci = y - a.off_y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cj = j0 + k - a.off_x;
+            const bool in = ci >= 0 && ci < a.center_h && cj >= 0 && cj < a.center_w;
+            const unsigned co = in ? ((unsigned)ci * (unsigned)a.center_w + (unsigned)cj) * 3u : 0u;
+            const unsigned cc = co < clast ? co : clast;
+            unsigned int c;
+            __builtin_memcpy(&c, center + cc, 4);
+            c = in ? ((c >> (8 * (co - cc))) & 0x00ffffffu) : 0u;
+            const unsigned w = px[k];
+            const unsigned avg = (w & c) + (((w ^ c) & 0x00fefefeu) >> 1);
+            px[k] = (w != 0u && c != 0u) ? avg : (w | c);
+        }
+    }
+    uint8_t *o = out + ((size_t)(y - a.row_begin) * (size_t)a.final_w) * 3 + (unsigned)j0 * 3u;
+    if (npx == 4) {
+        Bytes12 v;
+        v.a = px[0] | (px[1] << 24);
+        v.b = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);
+        v.c = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);
+        __builtin_memcpy(o, &v, 12);
+    } else {
+        for (int k = 0; k < npx; ++k) {
+            o[3 * k] = (uint8_t)(px[k] & 0xff);
+            o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
+            o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
+        }
+    }
+}
+
+typedef int walk_rsrc_t __attribute__((ext_vector_type(4)));
+
+// One source pixel's dword through the image's buffer descriptor, hidden from hipcc's wait counting (with a set of gathers
+// carried around the loop hipcc drains the queue where the set is only issued): the destination is not valid until
+// walk_wait() below names it.
+#ifndef APAP_WALK_ASM
+#define APAP_WALK_ASM 0      // 1: the gathers as inline asm with a hand-placed wait (measured 2.5x SLOWER than the loads hipcc counts)
+#endif
+#ifndef APAP_WALK_NOP
+#define APAP_WALK_NOP "s_nop 0"
+#endif
+__device__ __forceinline__ unsigned walk_gather(unsigned off, walk_rsrc_t rsrc, __amdgpu_buffer_rsrc_t rs) {
+#if APAP_WALK_ASM
+    unsigned v;
+    asm volatile(APAP_WALK_NOP "\n\tbuffer_load_dword %0, %1, %2, 0 offen\n\ts_nop 0" : "=v"(v) : "v"(off), "s"(rsrc));
+    return v;
+#else
+    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
+#endif
+}
+
+// Everything issued so far has landed, the set `px` in particular.
+template <int S>
+__device__ __forceinline__ void walk_wait(unsigned (&px)[S][4]) {
+#if APAP_WALK_ASM
+    if constexpr (S == 1)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]));
+    else if constexpr (S == 2)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]), "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]),
+                       "+v"(px[1][3]));
+    else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]), "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]),
+                       "+v"(px[1][3]), "+v"(px[2][0]), "+v"(px[2][1]), "+v"(px[2][2]), "+v"(px[2][3]), "+v"(px[3][0]), "+v"(px[3][1]),
+                       "+v"(px[3][2]), "+v"(px[3][3]));
+#endif
+}
+
+// the float32 estimate of one pixel (k_warp_fast's arithmetic): source byte offset or the "outside" marker, and whether the
+// pixel is in doubt (estimate within the cell's window of an integer, or the image's last pixel, which the buffer load must not
+// fetch)
+__device__ __forceinline__ unsigned walk_estimate(const FastConst &c, int k, float dy, int img_w, int img_h, unsigned last_off, bool &doubt) {
+    const float num_x = __builtin_fmaf(c.bx[k], dy, c.nx0[k]);
+    const float num_y = __builtin_fmaf(c.by[k], dy, c.ny0[k]);
+    const float den = __builtin_fmaf(c.h7[k], dy, c.dn0[k]);
+    const float rc = __builtin_amdgcn_rcpf(den);
+    const int fx = (int)(num_x * rc), fy = (int)(num_y * rc);      // 10.22 fixed point; NaN -> 0
+    const int ix = c.n0x[k] + (fx >> kFastFracBits), iy = c.n0y[k] + (fy >> kFastFracBits);
+    const unsigned lo = min((unsigned)fx << (32 - kFastFracBits), (unsigned)fy << (32 - kFastFracBits));
+    const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
+    const unsigned o = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
+    doubt = (lo < c.thr[k]) | (o == last_off);
+    return o;
+}
+
+// exact_offset() with the cell's inverse taken from registers (the float32 values ARE the stored inverse: fexact)
+__device__ __forceinline__ unsigned exact_offset_from(const float (&e)[9], int i, int j, int off_x, int off_y, int img_w, int img_h) {
+    Hinv9 h;
+    h.a = make_double2((double)e[0], (double)e[1]);
+    h.b = make_double2((double)e[2], (double)e[3]);
+    h.c = make_double2((double)e[4], (double)e[5]);
+    h.d = make_double2((double)e[6], (double)e[7]);
+    h.e = make_double2((double)e[8], 0.0);
+    double tx, ty;
+    target_from(h, (double)(j - off_x), (double)(i - off_y), tx, ty);
+    const int ix = (int)tx, iy = (int)ty;
+    const bool ok = (tx > 0.0) & (ty > 0.0) & (ix < img_w) & (iy < img_h);
+    return ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
+}
+
+template <bool kBlend, int S>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_warp_walk(const uint8_t *__restrict__ img_all, const double *__restrict__ hinv_all,
+                                                   const int *__restrict__ lut, const float4 *__restrict__ frec_all,
+                                                   const float4 *__restrict__ fexact_all,
+                                                   const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
+                                                   uint8_t *__restrict__ out_all, const uint8_t *__restrict__ center_all,
+                                                   const WalkGeo a) {
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    unsigned u0 = gw * a.per + min(gw, a.rem);
+    const unsigned u1 = u0 + a.per + (gw < a.rem ? 1u : 0u);
+    if (u0 >= u1) return;
+    const unsigned img_bytes = (unsigned)a.img_h * (unsigned)a.img_w * 3u;
+    const unsigned last_off = img_bytes - 3u;      // byte offset of the image's very last pixel
+    const unsigned clast = kBlend ? (unsigned)a.center_h * (unsigned)a.center_w * 3u - 4u : 0u;
+    const unsigned rec_stride = (unsigned)(a.mesh_cols + 1);
+    while (u0 < u1) {       // one pass per (pair, column block) the wave's share touches: usually one, sometimes two
+        const unsigned seg = u0 / (unsigned)a.row_count;
+        const unsigned yrel = u0 - seg * (unsigned)a.row_count;
+        const unsigned pair = seg / a.nbx, cb = seg - pair * a.nbx;
+        const unsigned n_rows = min((unsigned)a.row_count - yrel, u1 - u0);
+        u0 += n_rows;
+        const uint8_t *__restrict__ img = img_all + (long long)pair * a.st.img;
+        uint8_t *__restrict__ out = out_all + (long long)pair * a.st.out;
+        const uint8_t *__restrict__ center = kBlend ? center_all + (long long)pair * a.st.center : nullptr;
+        const double *__restrict__ hinv_pad = hinv_all + (long long)pair * a.st.hinv;
+        const float4 *__restrict__ frec = frec_all + (long long)pair * a.st.frec;
+        const float4 *__restrict__ fexact = fexact_all + (long long)pair * a.st.frec;
+        // the image as a buffer: offsets at or beyond img_bytes (the "outside" marker) read as 0
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), (short)0, (int)img_bytes, 0x00020000);
+        walk_rsrc_t rsv, rsrc;
+        __builtin_memcpy(&rsv, &rs, 16);
+        rsrc.x = __builtin_amdgcn_readfirstlane(rsv.x);       // the asm operand must be four scalar registers
+        rsrc.y = __builtin_amdgcn_readfirstlane(rsv.y);
+        rsrc.z = __builtin_amdgcn_readfirstlane(rsv.z);
+        rsrc.w = __builtin_amdgcn_readfirstlane(rsv.w);
+        // the last pixel's three bytes: the dword one byte earlier, shifted (no byte beyond the image is touched)
+        unsigned last_px;
+        __builtin_memcpy(&last_px, img + (img_bytes - 4u), 4);
+        last_px >>= 8;
+        const int y_begin = a.row_begin + (int)yrel, y_end = y_begin + (int)n_rows;
+        const int j0 = ((int)cb * 64 + lane) * 4;
+        const bool active = j0 < a.final_w;
+        const int j0c = active ? j0 : ((a.final_w - 1) & ~3);        // idle lanes of the last block repeat its last group
+        const int npx = active ? min(4, a.final_w - j0) : 0;
+        const uint4 ce = *reinterpret_cast<const uint4 *>(fcol + j0c);
+        const unsigned cev[4] = {ce.x, ce.y, ce.z, ce.w};
+        unsigned col[4];
+        float dxf[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            col[k] = cev[k] & 0xffffu;
+            dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;
+        }
+        FastConst c;
+        unsigned cur = 0xfffffffeu;      // no cell row loaded yet
+        unsigned px[S][4];               // the gathered pixels of the stage in flight
+        unsigned patch = 0u;             // per lane: pixels of that stage that are the image's last pixel
+        int y_prev = -1;
+        int y = y_begin;
+        // row entries of the coming stage, prefetched (scalar loads)
+        uint2 en[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) en[t] = frow[(unsigned)min(y + t, y_end - 1)];
+        // A stage's gathers are in flight while the NEXT stage's row entries are fetched and its offsets computed; then they
+        // are waited for and stored, and the next stage's gathers go out into the same registers.
+        for (;;) {
+            unsigned off[S][4];
+            unsigned patch_new = 0u;
+            const int y_new = y < y_end ? y : -1;
+            if (y_new >= 0) {
+                unsigned rr[S];
+                float dyf[S];
+#pragma unroll
+                for (int t = 0; t < S; ++t) {
+                    rr[t] = __builtin_amdgcn_readfirstlane(en[t].x);
+                    dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(en[t].y));
+                }
+                y += S;
+                if (y < y_end) {
+#pragma unroll
+                    for (int t = 0; t < S; ++t) en[t] = frow[(unsigned)min(y + t, y_end - 1)];
+                }
+                unsigned long long doubt[S][4];     // lane masks (scalar registers)
+                unsigned long long any = 0;
+#pragma unroll
+                for (int t = 0; t < S; ++t) {
+                    if (rr[t] != cur) {     // the walk enters another cell row (wave-uniform)
+                        cur = rr[t];
+                        load_fast_const(c, frec, fexact, cur * rec_stride, col, dxf);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        bool d;
+                        off[t][k] = walk_estimate(c, k, dyf[t], a.img_w, a.img_h, last_off, d);
+                        doubt[t][k] = __builtin_amdgcn_ballot_w64(d);
+                        any |= doubt[t][k];
+                    }
+                }
+                if (any != 0) {
+                    // some pixel of the stage is in doubt (a few stages in a hundred on BASELINE's configurations; every stage
+                    // of a mesh the estimate has no bound for): the exact float64 sequence for those pixels.  The cell's stored
+                    // inverse is in registers (fexact) when the pixel sits in the first or the last pixel's cell of the cell
+                    // row whose constants are loaded - no dependent load, the wave does not fall behind the others; any
+                    // other pixel (a third cell inside the lane's four, an earlier cell row of this stage, a float64 grid,
+                    // a pixel outside every ordinary cell) takes the table path of k_warp_fast.
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int t = 0; t < S; ++t)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) bits |= ((doubt[t][k] >> lane) & 1ull) ? (1u << (t * 4 + k)) : 0u;
+                    while (bits != 0u) {
+                        const int idx = __builtin_ctz(bits);
+                        bits &= bits - 1u;
+                        const int t = idx >> 2, k = idx & 3;
+                        const int i = min(y_new + t, y_end - 1), j = min(j0c + k, a.final_w - 1);
+                        unsigned cr = rr[0], cc = col[0];
+#pragma unroll
+                        for (int q = 1; q < S; ++q) cr = t == q ? rr[q] : cr;
+#pragma unroll
+                        for (int q = 1; q < 4; ++q) cc = k == q ? col[q] : cc;
+                        const bool in_a = cc == col[0], in_b = cc == col[3];
+                        const float valid = in_a ? c.ea[9] : c.eb[9];
+                        unsigned o;
+                        if (cr == cur && (in_a || in_b) && valid != 0.0f) {
+                            float e[9];
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) e[q] = in_a ? c.ea[q] : c.eb[q];
+                            o = exact_offset_from(e, i, j, a.off_x, a.off_y, a.img_w, a.img_h);
+                        } else {
+                            o = exact_offset(hinv_pad, lut, a.mesh_rows, a.mesh_cols, a.final_h, cr, cc, i, j, a.off_x, a.off_y, a.img_w,
+                                             a.img_h);
+                        }
+                        if (o == last_off) {
+                            patch_new |= 1u << idx;
+                            o = 0xffffffffu;
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < S; ++tt)
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) off[tt][kk] = (idx == tt * 4 + kk) ? o : off[tt][kk];
+                    }
+                }
+            }
+            if (y_prev >= 0) {
+                walk_wait<S>(px);
+                const bool patched = __builtin_amdgcn_ballot_w64(patch != 0u) != 0;
+#pragma unroll
+                for (int t = 0; t < S; ++t) {
+                    const int yy = y_prev + t;
+                    if (yy >= y_end) break;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) px[t][k] &= 0x00ffffffu;
+                    if (patched) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) px[t][k] = ((patch >> (t * 4 + k)) & 1u) ? last_px : px[t][k];
+                    }
+                    if (active) walk_store_row<kBlend>(a, center, out, px[t], yy, j0, npx, clast);
+                }
+            }
+            if (y_new < 0) break;
+#pragma unroll
+            for (int t = 0; t < S; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) px[t][k] = walk_gather(off[t][k], rsrc, rs);
+            patch = patch_new;
+            y_prev = y_new;
+        }
+    }
+}
+
 // coordinates only (parity tests of the arithmetic of k_warp)
 __global__ __launch_bounds__(256) void k_warp_coords(const double *__restrict__ hinv_pad, int mesh_cols,
                                                      const int *__restrict__ lut, int final_w,
@@ -2530,7 +2932,11 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_FUSED_MAX_CELLS:
         case APAP_OPT_PLAN_CELLS: ok = value >= 0; break;
         case APAP_OPT_WARP_FAST:
+        case APAP_OPT_WARP_WALK:
         case APAP_OPT_OVERLAP_PCIE: ok = value == 0 || value == 1; break;
+        case APAP_OPT_WARP_WAVES: ok = value >= 4 && value <= 32 && value % 4 == 0; break;
+        case APAP_OPT_WARP_STAGE: ok = value == 1 || value == 2; break;
+        case APAP_OPT_WARP_MIN_RUN: ok = value >= 1; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
     }
     if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
@@ -2572,9 +2978,11 @@ size_t apap_solve_batch_workspace_bytes(apap_ctx *ctx, int n, int cells, int bat
 
 size_t apap_solve_workspace_bytes(apap_ctx *ctx, int n, int cells) { return apap_solve_batch_workspace_bytes(ctx, n, cells, 1); }
 
-int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+}  // extern "C"
+
+static int solve_batch_impl(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
                             int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
-                            int batch, void *d_work, size_t work_bytes, void *stream) {
+                            int batch, void *d_work, size_t work_bytes, void *stream, const WarpEmit &we) {
     if (!d_tables || !d_vertices || !d_denorms || !d_H || !d_work)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: null device pointer");
     if (n < 1 || cells < 1 || batch < 1 || batch > 65535 || vertices_stride < 0)
@@ -2605,10 +3013,10 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
         const dim3 grid((cells + 15) / 16, 1, batch);
         if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)
             hipLaunchKernelGGL(k_solve_small<false>, grid, dim3(kSmallThreads), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
-                               d_denorms, pick_rank, careful, d_H, bs);
+                               d_denorms, pick_rank, careful, d_H, bs, we);
         else
             hipLaunchKernelGGL(k_solve_small<true>, grid, dim3(kSmallThreads), 0, s, d_tables, n, d_vertices, cells, gamma, inv_sigma,
-                               d_denorms, pick_rank, careful, d_H, bs);
+                               d_denorms, pick_rank, careful, d_H, bs, we);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
         return APAP_OK;
@@ -2635,14 +3043,51 @@ int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const 
         const dim3 grid(p.cell_tiles, 1, batch);
         if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)
             hipLaunchKernelGGL(k_eigen_denorm<false>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
-                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful);
+                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful, we);
         else
             hipLaunchKernelGGL(k_eigen_denorm<true>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
-                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful);
+                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful, we);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
     return APAP_OK;
+}
+
+extern "C" {
+
+int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+                            int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
+                            int batch, void *d_work, size_t work_bytes, void *stream) {
+    const WarpEmit none{};
+    return solve_batch_impl(ctx, d_tables, n, d_vertices, vertices_stride, cells, gamma, sigma, d_denorms, d_H, batch, d_work,
+                            work_bytes, stream, none);
+}
+
+int apap_solve_warp_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+                                 double gamma, double sigma, const double *d_denorms, float *d_H, int batch, void *d_work,
+                                 size_t work_bytes, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w,
+                                 const double *d_mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
+                                 void *d_warp_work, size_t warp_work_bytes, int *d_status, void *stream) {
+    if (!d_mesh_w || !d_mesh_h || !d_warp_work || !d_status)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_warp_batch_device: null device pointer");
+    if (mesh_rows < 1 || mesh_cols < 1 || n_w < 1 || n_h < 1 || final_w < 1 || final_h < 1 || batch < 1)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_warp_batch_device: bad size");
+    if (n_w > kMaxEdges || n_h > kMaxEdges || mesh_rows >= 65535 || mesh_cols >= 65535 ||
+        (unsigned long long)mesh_rows * (unsigned long long)mesh_cols * APAP_HINV_STRIDE * sizeof(double) >= (1ull << 32))
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_warp_batch_device: mesh too large for the warp's lookup tables (solve and "
+                                                "warp it with the separate entry points)");
+    const size_t need = apap_warp_batch_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h, batch);
+    if (warp_work_bytes < need)
+        return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_warp_batch_device: warp workspace %zu < %zu bytes", warp_work_bytes, need);
+    const WarpWork ww = warp_work_layout(d_warp_work, mesh_rows, mesh_cols, final_w, final_h, batch);
+    WarpEmit we;
+    we.hinv_pad = ww.hinv_pad; we.frec = ww.frec; we.fexact = ww.fexact;
+    we.hinv_stride = ww.hinv_stride; we.frec_stride = ww.frec_stride;
+    we.mesh_w = d_mesh_w; we.mesh_h = d_mesh_h; we.n_w = n_w; we.n_h = n_h;
+    we.mesh_rows = mesh_rows; we.mesh_cols = mesh_cols; we.final_w = final_w; we.final_h = final_h; we.off_x = off_x; we.off_y = off_y;
+    we.status = d_status;
+    return solve_batch_impl(ctx, d_tables, n, d_vertices, vertices_stride, mesh_rows * mesh_cols, gamma, sigma, d_denorms, d_H, batch,
+                            d_work, work_bytes, stream, we);
 }
 
 int apap_solve_device(apap_ctx *ctx, const double *d_table, int n, const double *d_vertices, int cells,
@@ -2733,7 +3178,7 @@ int warp_prologue(apap_ctx *ctx, const WarpArgs &a, WarpWork *ww, bool *fast_tab
                            ww->hinv_pad, Hinv_out, inv_blocks, a.mesh_w, a.n_w, a.mesh_h, a.n_h, a.mesh_rows, a.mesh_cols,
                            a.final_w, a.final_h, ww->lut, a.status, a.off_x, a.off_y, ww->frec, ww->fcol, ww->frow,
                            a.src_rows && geometry && per_cell && a.batch == 1 ? ww->src_rows : (int *)nullptr, ww->hinv_stride,
-                           ww->frec_stride);
+                           ww->frec_stride, ww->fexact);
     } else {
         if (per_cell) {
             ProfScope prof(ctx, APAP_PROF_INVERT, s);
@@ -2808,7 +3253,47 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
     // APAP_OPT_WARP_FAST (default 1): the float32-estimate kernel.  It is exact for any input, but a pixel the
     // estimate cannot decide costs a trip through the exact sequence, and every pixel of a cell wider than
     // 254 pixels is one: meshes that coarse (on average) keep the all-float64 strip kernel.
-    if (strips && fast_tables && apap::opt(ctx, APAP_OPT_WARP_FAST) && final_w / mesh_cols <= 128 && final_h / mesh_rows <= 128) {
+    const bool fast_ok = strips && fast_tables && apap::opt(ctx, APAP_OPT_WARP_FAST) && final_w / mesh_cols <= 128 &&
+                         final_h / mesh_rows <= 128;
+    const unsigned nbx = (unsigned)((final_w + 255) / 256);
+    const unsigned long long wave_rows = (unsigned long long)batch * nbx * (unsigned long long)row_count;
+    if (fast_ok && apap::opt(ctx, APAP_OPT_WARP_WALK) && wave_rows < (1ull << 31)) {
+        // persistent column-walk form: the grid is sized to the chip, every wave walks a contiguous share of the wave-rows
+        ProfScope prof(ctx, APAP_PROF_WARP, s);
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        int wpc = apap::opt(ctx, APAP_OPT_WARP_WAVES);                 // resident waves per CU: 4-wave blocks, LDS-capped
+        const int bpc = wpc / 4 < 1 ? 1 : wpc / 4;
+        // small canvases: fewer waves, so that a wave still has a run of rows to pipeline
+        const unsigned long long min_rows = (unsigned long long)apap::opt(ctx, APAP_OPT_WARP_MIN_RUN);
+        unsigned long long blocks = (unsigned long long)cus * bpc;
+        if (wave_rows / min_rows < blocks * 4) blocks = (wave_rows / min_rows + 3) / 4;
+        if (blocks < 1) blocks = 1;
+        const unsigned waves = (unsigned)blocks * 4u;
+        WalkGeo w;
+        w.st = st;
+        w.img_h = img_h; w.img_w = img_w; w.mesh_rows = mesh_rows; w.mesh_cols = mesh_cols; w.final_w = final_w; w.final_h = final_h;
+        w.off_x = off_x; w.off_y = off_y; w.center_h = center_h; w.center_w = center_w; w.row_begin = row_begin; w.row_count = row_count;
+        w.nbx = nbx;
+        w.per = (unsigned)(wave_rows / waves);
+        w.rem = (unsigned)(wave_rows % waves);
+        // dynamic LDS the kernel never touches: it caps the blocks a CU takes at `bpc`, so that the dispatcher spreads the
+        // grid evenly (160 KiB per CU; a block may ask for 64 KiB at most without an attribute)
+        size_t lds = (size_t)(160 * 1024) / (size_t)(bpc + 1) + 1024;
+        if (lds > 64 * 1024) lds = 64 * 1024;
+        const int stage = apap::opt(ctx, APAP_OPT_WARP_STAGE);
+#define APAP_LAUNCH_WALK(S_)                                                                                         \
+    if (d_center)                                                                                                    \
+        hipLaunchKernelGGL((k_warp_walk<true, S_>), dim3((unsigned)blocks), dim3(256), lds, s, d_img, hinv_pad, lut, ww.frec, ww.fexact, ww.fcol, \
+                           ww.frow, d_out, d_center, w);                                                             \
+    else                                                                                                             \
+        hipLaunchKernelGGL((k_warp_walk<false, S_>), dim3((unsigned)blocks), dim3(256), lds, s, d_img, hinv_pad, lut, ww.frec, ww.fexact, ww.fcol, \
+                           ww.frow, d_out, (const uint8_t *)nullptr, w)
+        if (stage >= 2) { APAP_LAUNCH_WALK(2); }
+        else { APAP_LAUNCH_WALK(1); }
+#undef APAP_LAUNCH_WALK
+    } else if (fast_ok) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;
 #ifndef APAP_K3_BLOCK

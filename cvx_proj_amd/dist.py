@@ -132,6 +132,84 @@ def hip_warp_batch(imgs, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, shap
     return out, status
 
 
+class WarpPlan:
+    """One mesh / canvas geometry's warp workspace, kept between pairs (what the resident callers - ``Pipeline``, ``bench.py`` -
+    hold): the canvas row / column -> cell tables are built ONCE, here (``APAP_WARP_GEOMETRY``: they depend on the edges,
+    the canvas size and the offsets only); ``solve()`` is the per-cell solve whose tail leaves every cell warp ready in
+    this workspace (``apap_solve_warp_batch_device``); ``cells()`` does that for a grid that came from elsewhere
+    (``APAP_WARP_CELLS``); ``gather()`` is K3 alone (``APAP_WARP_GATHER``).  ``batch`` pairs share the geometry."""
+
+    def __init__(self, mesh, shape, final_w, final_h, off_x, off_y, dev, batch=1, ctx=None):
+        self.rows, self.cols = shape
+        self.geo = (int(final_w), int(final_h), int(off_x), int(off_y))
+        self.dev, self.batch, self.ctx = dev, int(batch), ctx
+        self.mesh_w = torch.from_numpy(np.ascontiguousarray(mesh[0], dtype=np.float64)).to(dev)
+        self.mesh_h = torch.from_numpy(np.ascontiguousarray(mesh[1], dtype=np.float64)).to(dev)
+        self.nbytes = _native.lib().apap_warp_batch_workspace_bytes(self.rows, self.cols, self.geo[0], self.geo[1], self.batch)
+        if not self.nbytes:
+            raise ValueError("WarpPlan: bad geometry")
+        self.work = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._phase(_native.WARP_GEOMETRY)
+
+    def _phase(self, phases, imgs=None, H=None, out=None, centers=None, rows=None, hinv_out=None):
+        fw, fh, ox, oy = self.geo
+        row_begin, row_count = (0, fh) if rows is None else rows
+        i_ptr, i_stride, ih, iw = None, 0, 0, 0
+        if imgs is not None:
+            one = imgs.dim() == 3
+            ih, iw = (imgs.shape[0], imgs.shape[1]) if one else (imgs.shape[1], imgs.shape[2])
+            i_ptr, i_stride = imgs.data_ptr(), 0 if one else ih * iw * 3
+        c_ptr, c_stride, ch, cw = None, 0, 0, 0
+        if centers is not None:
+            one_c = centers.dim() == 3
+            ch, cw = (centers.shape[0], centers.shape[1]) if one_c else (centers.shape[1], centers.shape[2])
+            c_ptr, c_stride = centers.data_ptr(), 0 if one_c else ch * cw * 3
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _native.check(_native.lib().apap_warp_batch_device(
+            _native._h(self.ctx), i_ptr, i_stride, ih, iw, c_ptr, c_stride, ch, cw, None if H is None else H.data_ptr(), self.rows,
+            self.cols, self.mesh_w.data_ptr(), self.mesh_w.numel(), self.mesh_h.data_ptr(), self.mesh_h.numel(), fw, fh, ox, oy,
+            row_begin, row_count, None if out is None else out.data_ptr(), row_count * fw * 3,
+            None if hinv_out is None else hinv_out.data_ptr(), self.batch, int(phases), self.work.data_ptr(), self.nbytes,
+            self.status.data_ptr(), ctypes.c_void_p(stream)))
+
+    def solve(self, tables, denorms, vertices, gamma, sigma, out=None, work=None):
+        """``tables`` (B, n, 32) or (n, 32), ``denorms`` (B, 36) or (36,), ``vertices`` (cells, 2) -> H (B * cells, 9) float32, and
+        every cell's inverse / record / exact floats in this plan's workspace."""
+        if not tables.is_cuda:
+            raise _native.ApapError(_native.ERR_NO_DEVICE, "WarpPlan.solve needs CUDA/HIP tensors; there is no CPU fallback")
+        n = tables.shape[-2]
+        cells = self.rows * self.cols
+        if vertices.shape[0] != cells:
+            raise ValueError(f"WarpPlan.solve: {vertices.shape[0]} vertices for a {self.rows} x {self.cols} mesh")
+        H = out if out is not None else torch.empty((self.batch * cells, 9), dtype=torch.float32, device=self.dev)
+        lib = _native.lib()
+        nb = max(lib.apap_solve_batch_workspace_bytes(_native._h(self.ctx), n, cells, self.batch), 256)
+        if work is None or work.numel() < nb:
+            work = torch.empty(nb, dtype=torch.uint8, device=self.dev)
+        fw, fh, ox, oy = self.geo
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _native.check(lib.apap_solve_warp_batch_device(
+            _native._h(self.ctx), tables.data_ptr(), n, vertices.data_ptr(), 0, float(gamma), float(sigma), denorms.data_ptr(),
+            H.data_ptr(), self.batch, work.data_ptr(), work.numel(), self.rows, self.cols, self.mesh_w.data_ptr(), self.mesh_w.numel(),
+            self.mesh_h.data_ptr(), self.mesh_h.numel(), fw, fh, ox, oy, self.work.data_ptr(), self.nbytes, self.status.data_ptr(),
+            ctypes.c_void_p(stream)))
+        return H
+
+    def cells(self, H, hinv_out=None):
+        """Per-cell set-up from a grid that was not solved into this plan (``H`` (B * cells, 9) float32)."""
+        self._phase(_native.WARP_CELLS, H=H, hinv_out=hinv_out)
+
+    def gather(self, imgs, out=None, centers=None, rows=None):
+        """K3: ``imgs`` (B, h, w, 3) or (h, w, 3) -> canvases (B, rows, final_w, 3)."""
+        fw, fh, _, _ = self.geo
+        n = fh if rows is None else rows[1]
+        if out is None:
+            out = torch.empty((self.batch, n, fw, 3), dtype=torch.uint8, device=self.dev)
+        self._phase(_native.WARP_GATHER, imgs=imgs, out=out, centers=centers, rows=rows)
+        return out
+
+
 class ShardedSolver:
     """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
 

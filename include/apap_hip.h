@@ -125,7 +125,14 @@ typedef struct apap_ctx apap_ctx;
                                       whatever the call holds - a shard of a mesh (cvx_proj_amd/dist.py) then sums every
                                       cell's keypoints in the order the whole mesh would on one GPU: the same bits for any
                                       number of ranks, at the price of fewer, larger blocks per GPU                      */
-#define APAP_OPT_COUNT 11
+#define APAP_OPT_WARP_WALK 11       /* K3 form: 0 = one strip of APAP_OPT_WARP_ROWS rows per wave; 1 = the persistent column-walk kernel:
+                                      a grid sized to the chip, every wave walks down a contiguous share of the canvas rows of one
+                                      256-pixel column block, software-pipelined (same canvas, byte for byte)                    */
+#define APAP_OPT_WARP_WAVES 12      /* tuning, column-walk form: resident waves per CU (a multiple of 4; default 16)              */
+#define APAP_OPT_WARP_STAGE 13      /* tuning, column-walk form: canvas rows per pipeline stage (1, 2; default 2)                   */
+#define APAP_OPT_WARP_MIN_RUN 14    /* tuning, column-walk form: small canvases get fewer waves so that a wave keeps at least this
+                                      many rows to pipeline (default 8)                                                            */
+#define APAP_OPT_COUNT 15
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);
@@ -251,6 +258,20 @@ size_t apap_solve_batch_workspace_bytes(apap_ctx *ctx, int n, int cells, int bat
 int apap_solve_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
                             int cells, double gamma, double sigma, const double *d_denorms, float *d_H,
                             int batch, void *d_work, size_t work_bytes, void *stream);
+
+/* The solve of a caller that WARPS NEXT (apap.py:240-243 followed by :186-217 - the reference's own sequence): the same
+ * kernels as apap_solve_batch_device with the warp's per-cell set-up riding in the eigen-solve kernel's tail, where it costs
+ * a fraction of a launch of its own: every cell leaves, beside its float32 H, its inverse, its float32-estimate record and its
+ * exact-path floats in the warp workspace - what APAP_WARP_CELLS would compute from the stored grid, bit for bit (one
+ * device function serves both).  The warp that follows runs apap_warp_batch_device(... phases = APAP_WARP_GATHER ...) on that
+ * workspace (APAP_WARP_GEOMETRY once per mesh / canvas geometry, before or after).  cells = mesh_rows * mesh_cols; the mesh
+ * edges, canvas size and offsets are the warp's.  d_status: the warp's status word (bit 0: a singular cell).  Meshes beyond
+ * 4096 edges per axis: APAP_ERR_INVALID_ARG (solve and warp them with the separate entry points). */
+int apap_solve_warp_batch_device(apap_ctx *ctx, const double *d_tables, int n, const double *d_vertices, long long vertices_stride,
+                                 double gamma, double sigma, const double *d_denorms, float *d_H, int batch, void *d_work,
+                                 size_t work_bytes, int mesh_rows, int mesh_cols, const double *d_mesh_w, int n_w,
+                                 const double *d_mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y,
+                                 void *d_warp_work, size_t warp_work_bytes, int *d_status, void *stream);
 
 /* The weights tensor alone: d_W cells x n doubles. */
 int apap_weights_device(apap_ctx *ctx, const double *d_table, int n, const double *d_vertices, int cells,

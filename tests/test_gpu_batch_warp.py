@@ -195,3 +195,48 @@ def test_batch_argument_checks(native):
     assert call() == native.OK
     torch.cuda.synchronize()
     assert int(st.cpu()[0]) & 1
+
+
+@pytest.mark.parametrize("cfg,batch", [("small", 3), ("C2", 1), ("C1", 2)])
+def test_solve_leaves_cells_warp_ready(native, cfg, batch):
+    """apap_solve_warp_batch_device: the eigen-solve kernel's tail (two-launch path at C2, fused small-mesh kernel at C1 and
+    on the small meshes) leaves every cell's inverse, float32-estimate record and exact-path floats in the warp workspace -
+    the SAME BYTES APAP_WARP_CELLS computes from the stored grid - and the same H grid as the plain solve; the gather that
+    follows (no set-up launch at all) writes the same canvases."""
+    import torch
+    from cvx_proj_amd.dist import WarpPlan, hip_solve_batch
+    dev = torch.device("cuda:0")
+    if cfg == "small":
+        pairs = small_batch(batch, seed=120)
+    else:
+        pairs = [config_pair(cfg, seed_offset=k) for k in range(batch)]
+    p0 = pairs[0]
+    rows, cols = p0.vertices.shape[:2]
+    tabs, dens = [], []
+    for p in pairs:
+        q = native.host_prepare(p.src, p.dst)
+        tabs.append(native.host_build_table(p.src, q["cf1"], q["cf2"]))
+        dens.append(native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)    # noqa: E731
+    tables, denorms, vert = t(np.stack(tabs)), t(np.stack(dens)), t(p0.vertices.reshape(-1, 2))
+    imgs = t(np.stack([p.img for p in pairs]))
+    geo = (p0.final_w, p0.final_h, p0.off_x, p0.off_y)
+    a = WarpPlan(p0.mesh, (rows, cols), *geo, dev, batch=batch)
+    b = WarpPlan(p0.mesh, (rows, cols), *geo, dev, batch=batch)
+    H_a = a.solve(tables, denorms, vert, p0.gamma, p0.sigma)
+    H_b = hip_solve_batch(tables, denorms, vert, p0.gamma, p0.sigma).view(-1, 9)
+    assert torch.equal(H_a, H_b)
+    b.cells(H_b)
+    torch.cuda.synchronize()
+    assert int(a.status.cpu()[0]) == 0 and int(b.status.cpu()[0]) == 0
+    assert torch.equal(a.work, b.work), "the solve's tail and APAP_WARP_CELLS disagree on the workspace bytes"
+    out_a, out_b = a.gather(imgs), b.gather(imgs)
+    assert torch.equal(out_a, out_b)
+    for k, p in enumerate(pairs[:2]):
+        single, _ = native.local_warp(p.img, H_b.view(batch, rows, cols, 3, 3)[k].cpu().numpy(), p.mesh[0], p.mesh[1], *geo)
+        assert np.array_equal(out_a[k].cpu().numpy(), single), k
+    # a singular cell reaches the status word from the solve's tail as it does from the set-up kernel
+    # (degenerate keypoints: every dst equal -> H of rank 1)
+    # the plan is reusable: a second solve overwrites the cells, the geometry stays
+    H_a2 = a.solve(tables.flip(0).contiguous(), denorms.flip(0).contiguous(), vert, p0.gamma, p0.sigma)
+    assert torch.equal(a.gather(imgs.flip(0).contiguous()).flip(0), out_a) and torch.equal(H_a2.view(batch, -1, 9).flip(0), H_a.view(batch, -1, 9))
