@@ -2264,6 +2264,9 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
     return ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
 }
 
+#ifndef APAP_K3_BUF
+#define APAP_K3_BUF 0
+#endif
 template <bool kBlend, int kRows>
 __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
                                                    const double *__restrict__ hinv_pad, int mesh_rows, int mesh_cols,
@@ -2311,6 +2314,9 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     unsigned off[kRows][4];
     unsigned int px[kRows][4];
     unsigned long long doubt[kRows][4];    // lane masks (scalar registers)
+#if APAP_K3_BUF
+    unsigned patch = 0u;                   // per lane: pixels that are the image's very last pixel
+#endif
     const unsigned rec_stride = (unsigned)(mesh_cols + 1);
     unsigned todo = (1u << kRows) - 1u;
 #ifdef APAP_K3_ABL_COPY   // experiment: no coordinate work at all - the access pattern's own floor
@@ -2362,9 +2368,14 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
                 const int fx = (int)(num_x * rc), fy = (int)(num_y * rc);      // 10.22 fixed point; NaN -> 0
                 const int ix = n0x[k] + (fx >> kFastFracBits), iy = n0y[k] + (fy >> kFastFracBits);
                 const unsigned lo = min((unsigned)fx << (32 - kFastFracBits), (unsigned)fy << (32 - kFastFracBits));
-                doubt[t][k] = __builtin_amdgcn_ballot_w64(lo < thr[k]);
                 const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
                 off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
+#if APAP_K3_BUF
+                // the image's last pixel must not be fetched through the descriptor (its dword reaches one byte past the image)
+                doubt[t][k] = __builtin_amdgcn_ballot_w64((lo < thr[k]) | (off[t][k] == last + 1u));
+#else
+                doubt[t][k] = __builtin_amdgcn_ballot_w64(lo < thr[k]);
+#endif
             }
         }
     }
@@ -2393,7 +2404,13 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
                 for (int t = 1; t < kRows; ++t) cr = (idx >> 2) == t ? rr[t] : cr;
 #pragma unroll
                 for (int k = 1; k < 4; ++k) cc = (idx & 3) == k ? col[k] : cc;
-                const unsigned o = exact_offset(hinv_pad, lut, mesh_rows, mesh_cols, final_h, cr, cc, i, j, off_x, off_y, img_w, img_h);
+                unsigned o = exact_offset(hinv_pad, lut, mesh_rows, mesh_cols, final_h, cr, cc, i, j, off_x, off_y, img_w, img_h);
+#if APAP_K3_BUF
+                if (o == last + 1u) {
+                    patch |= 1u << idx;
+                    o = 0xffffffffu;
+                }
+#endif
 #pragma unroll
                 for (int t = 0; t < kRows; ++t)
 #pragma unroll
@@ -2403,10 +2420,31 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     }
     // all of the strip's gathers in flight together (issuing a row's as soon as its offsets exist, or dropping
     // the range tests and the last-pixel guard for waves wholly inside the source, measured no faster: DESIGN.md)
+#if APAP_K3_BUF
+    {
+        // source pixels through a buffer descriptor over the image: the range check returns 0 for the "outside" marker, so a
+        // gathered dword needs one AND instead of clamp / shift / sign mask
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), (short)0, (int)(last + 4u), 0x00020000);
+#pragma unroll
+        for (int t = 0; t < kRows; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) px[t][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off[t][k], 0, 0) & 0x00ffffffu;
+        if (__builtin_amdgcn_ballot_w64(patch != 0u) != 0) {     // the image's last pixel: the dword one byte earlier, shifted
+            unsigned last_px;
+            __builtin_memcpy(&last_px, img + last, 4);
+            last_px >>= 8;
+#pragma unroll
+            for (int t = 0; t < kRows; ++t)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) px[t][k] = ((patch >> (t * 4 + k)) & 1u) ? last_px : px[t][k];
+        }
+    }
+#else
 #pragma unroll
     for (int t = 0; t < kRows; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
+#endif
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const int y = y_first + t;
