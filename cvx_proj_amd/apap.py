@@ -80,6 +80,10 @@ class LazyWeights:
             return w[(Ellipsis,) + key[2:]] if len(key) == 3 else w
         return self.materialize()[idx]
 
+    def __setitem__(self, idx, value):
+        """A caller that writes into the reference's array (``W[i, j] = ...``) gets the real array from then on."""
+        self.materialize()[idx] = value
+
     def __len__(self):
         return self.shape[0]
 
@@ -184,7 +188,7 @@ class APAP:
         (what the reference does); ``return_weights=False`` returns ``None``."""
         H, W = _native.local_homography(src_point, dst_point, vertices, self.gamma, self.sigma,
                                         want_weights=(return_weights == "eager"), device=self.device, ctx=self.ctx)
-        if return_weights is True:
+        if return_weights and not (isinstance(return_weights, str) and return_weights == "eager"):      # any truthy value but "eager"
             W = LazyWeights(src_point, vertices, self.gamma, self.sigma, device=self.device, ctx=self.ctx)
         return H, W
 

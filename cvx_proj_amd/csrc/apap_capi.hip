@@ -309,11 +309,16 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     const size_t range_ints = (size_t)mesh_rows * 2 + 2;
     int rc = pipe_prepare(pool, dev, (size_t)2 * chunks + bands + 2, range_ints * sizeof(int) + 64);
     if (rc) return rc;
-    // Only the three big buffers are pinned, and only when no two of them share a page: two registrations that
-    // overlap in a page (arrays that malloc placed back to back - numpy's `H.copy()` followed by `np.empty_like(H)`
-    // did, with the grid and its inverse pinned too) ended in a GPU fault "write access to a read-only page" on
-    // this stack.  The grid, its inverse and the edges travel as ordinary pageable copies (1.4 MB, on the kernel
-    // stream, while the image chunks are already going up).
+    // Only the three big buffers are pinned, and only when no two of them share a page.  History: with the grid and its
+    // inverse pinned as well (numpy's `H.copy()` followed by `np.empty_like(H)`: back to back) one run of round 3 ended in a
+    // GPU fault "write access to a read-only page", attributed then to the two registrations sharing a page.  Round 4's
+    // stand-alone reproducer of exactly that layout (tools/hostreg_pages.hip, profiles/r04_hostreg_pages.txt: both ranges
+    // registered, DMA in both directions and at once, a kernel reading one and writing the other through the device
+    // pointers, either unregistration order) runs clean on this stack: the shared page was NOT the cause, which stays
+    // unknown (no log of the fault survived).  The rule is kept because it costs nothing: pinning 1.4 MB buys nothing (the
+    // grid, its inverse and the edges travel as pageable copies on the kernel stream while the image chunks are already going
+    // up), and page-disjoint registrations are the case every test exercises (tests/test_gpu_parity.py:
+    // test_overlapped_host_warp_on_buffers_that_share_pages runs both layouts).
     auto pages_overlap = [](const void *a, size_t na, const void *b, size_t nb) {
         const uintptr_t pa0 = (uintptr_t)a >> 12, pa1 = ((uintptr_t)a + na - 1) >> 12;
         const uintptr_t pb0 = (uintptr_t)b >> 12, pb1 = ((uintptr_t)b + nb - 1) >> 12;
@@ -398,7 +403,9 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     stamp("set-up enqueued");
     APAP_HIP_TRY(hipEventSynchronize(e_setup));
     stamp("set-up done");
-    const bool irregular = (h_rng[2 * mesh_rows] & 1) != 0;
+    // (the host's cell_row_of below is a binary search: valid on increasing edges only; the device's running-maximum table also
+    // serves merely swapped edges, whose pixels all sit in ordinary cells and do not set the flag bit)
+    const bool irregular = (h_rng[2 * mesh_rows] & 1) != 0 || !std::is_sorted(mesh_h, mesh_h + n_h);
     auto cell_row_of = [&](int y) {     // "first k with y < mesh_h[k]" - 1 on increasing edges
         const int k = (int)(std::upper_bound(mesh_h, mesh_h + n_h, (double)y) - mesh_h) - 1;
         return std::min(std::max(k, 0), mesh_rows - 1);

@@ -245,9 +245,14 @@ class ShardedSolver:
         self.rows, self.cols = pair.vertices.shape[:2]
         self.cells_total = self.rows * self.cols
         if same_bits and solve_fn is hip_solve:
-            if ctx is None:
-                ctx = _native.Context()
-            ctx.set("plan_cells", self.cells_total)
+            # a context of the solver's own (the caller's keeps its options: APAP_OPT_PLAN_CELLS would change the kernel
+            # choice and the keypoint splits of every later solve made with it), carrying the caller's other options over
+            own = _native.Context()
+            if ctx is not None:
+                for name in _native.Context._NAMES:
+                    own.set(name, ctx.get(name))
+            own.set("plan_cells", self.cells_total)
+            ctx = own
         # a _native.Context (options, profiling) handed to the default HIP compute functions
         self._ctx = ctx
         self._kw = {"ctx": ctx} if ctx is not None else {}
@@ -365,8 +370,10 @@ class ShardedSolver:
         near-equal bands warped from the whole gathered grid."""
         p, d = self.pair, self.dist
         edges = np.asarray(p.mesh[1], dtype=np.float64)
+        # (edges that stop short of the canvas keep the unaligned bands: there the single-GPU path and the reference report an
+        # index error for the uncovered rows, apap.py:207 - opening the last edge to +inf would silently warp them)
         self._aligned = (self.world > 1 and len(edges) == self.rows + 1 and bool(np.all(np.diff(edges) > 0)) and edges[0] <= 0.0
-                         and bool(np.isfinite(edges).all()))
+                         and bool(np.isfinite(edges).all()) and edges[-1] >= p.final_h)
         if self._aligned:
             first = lambda k: int(min(max(np.ceil(edges[k]), 0.0), p.final_h)) if k < self.rows else p.final_h   # noqa: E731
             self.bands = [(first(ra), first(rb)) if rb > ra else (first(ra), first(ra)) for ra, rb in self.parts]

@@ -47,6 +47,8 @@ class Pipeline:
         self._h = _native._h(ctx)
         self._buf = {}              # name -> device tensor, grown on demand and reused between pairs
         self.timeline = {}          # milliseconds of the last run_pair, by stage (host clock, after the final sync)
+        self._plans = {}            # canvas geometry -> WarpPlan (lookup tables built once per geometry)
+        self._side = torch.cuda.Stream(self.dev)          # download of the .mat array beside the warp
 
     # ------------------------------------------------------------------ device memory
     def _get(self, name, shape, dtype):
@@ -96,19 +98,44 @@ class Pipeline:
         inlier mask and the 3 x 3 model come to the host: the canvas geometry is computed from them."""
         return _native.find_homography_ransac(src_pts, dst_pts, thresh, device=self.dev.index, ctx=self.ctx)
 
+    def _plan(self, mesh, rows, cols, fw, fh, ox, oy):
+        """The warp workspace of one mesh / canvas geometry: the canvas row / column -> cell tables are built when the geometry is
+        first seen (they do not depend on H) and kept - a CLI run over the pictures of one case, or a caller streaming pairs of one
+        size, meets a handful of geometries."""
+        from .dist import WarpPlan
+        key = (rows, cols, fw, fh, ox, oy, mesh.tobytes())
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 8:
+                self._plans.pop(next(iter(self._plans)))
+            plan = self._plans[key] = WarpPlan(mesh, (rows, cols), fw, fh, ox, oy, self.dev, batch=1, ctx=self.ctx)
+            plan.vertices = None        # the mesh's sample points on the device, kept with the geometry
+        return plan
+
     def run_pair(self, src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
                  other_img=None, center_img=None, want_grid=False):
         """Body of the reference's ``__main__`` between loading and saving (apap.py:238-264): returns
         ``(H_flat (m*m, 9) float64, canvas or None)`` (and the float32 H grid with ``want_grid``); the canvas is
-        the warped other image or, with ``center_img``, the blended stitch of apap.py:258-262."""
+        the warped other image or, with ``center_img``, the blended stitch of apap.py:258-262.
+
+        What overlaps (round 4): the solve is enqueued FIRST and the 25 MB source image (and the centre image) go up while it
+        runs (a copy from pageable memory blocks the host, not the GPU; a helper thread for the upload was measured: its copy and
+        the main thread's small uploads serialise in the runtime's pin-and-copy path and the set-up slows down under the GIL -
+        no gain); the solve's tail leaves every cell warp ready, so the warp is the gather kernel alone on tables whose
+        geometry half (and the mesh's vertices) were built when this canvas geometry was first seen; the ``.mat`` array comes
+        down on a side stream beside the warp; the canvas is the one copy left on the critical path."""
         import time
         torch, lib = self.torch, _native.lib()
         t0 = time.perf_counter()
         fw, fh, ox, oy = (int(v) for v in final_size(_Shape(center_shape), _Shape(other_shape), H_global))
         mesh = get_mesh((fw, fh), mesh_size + 1)
-        vertices = get_vertice((fw, fh), mesh_size, (ox, oy))
-        rows, cols = vertices.shape[:2]
+        rows = cols = int(mesh_size)
         cells = rows * cols
+        plan = None
+        with torch.cuda.device(self.dev):
+            if other_img is not None and mesh.shape[1] <= 4096:
+                plan = self._plan(mesh, rows, cols, fw, fh, ox, oy)     # lookup tables + vertices of this geometry: built once
+        vertices = None if plan is not None and plan.vertices is not None else get_vertice((fw, fh), mesh_size, (ox, oy))
         q = _native.host_prepare(src, dst)                                  # apap.py:132-140 in C
         table = _native.host_build_table(np.ascontiguousarray(src, np.float32), q["cf1"], q["cf2"])
         denorm = _native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
@@ -116,44 +143,61 @@ class Pipeline:
         t1 = time.perf_counter()
         with torch.cuda.device(self.dev):
             stream = self._stream()
+            main = torch.cuda.current_stream(self.dev)
             d_table = self._up("table", table, torch.float64)
             d_den = self._up("denorm", denorm, torch.float64)
-            d_vert = self._up("vertices", vertices.reshape(-1, 2), torch.float64)
+            if vertices is None:
+                d_vert = plan.vertices
+            else:
+                d_vert = self._up("vertices", vertices.reshape(-1, 2), torch.float64)
+                if plan is not None:
+                    plan.vertices = d_vert.clone()
             d_H = self._get("H", (cells, 9), torch.float32)
             nb = max(lib.apap_solve_workspace_bytes(self._h, n, cells), 256)
             d_work = self._get("solve_work", (nb,), torch.uint8)
-            _native.check(lib.apap_solve_device(self._h, d_table.data_ptr(), n, d_vert.data_ptr(), cells, float(gamma), float(sigma),
-                                                d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(), nb, stream))
+            if plan is not None:
+                # the solve that leaves every cell warp ready in the plan's workspace (apap_solve_warp_batch_device)
+                plan.status.zero_()
+                plan.solve(d_table, d_den, d_vert, float(gamma), float(sigma), out=d_H, work=d_work)
+            else:
+                _native.check(lib.apap_solve_device(self._h, d_table.data_ptr(), n, d_vert.data_ptr(), cells, float(gamma), float(sigma),
+                                                    d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(), nb, stream))
             # output stage apap.py:250-264 on the resident grid
             d_flat = self._get("flat", (cells, 9), torch.float64)
-            d_status = self._get("status", (1,), torch.int32)
-            d_status.zero_()
+            d_status = plan.status if plan is not None else self._get("status", (1,), torch.int32)     # one word for every stage
+            if plan is None:
+                d_status.zero_()
             _native.check(lib.apap_flatten_device(self._h, d_H.data_ptr(), cells, d_flat.data_ptr(), d_status.data_ptr(), stream))
+            flat_ready = torch.cuda.Event()
+            flat_ready.record(main)
             d_out = None
             if other_img is not None:
                 img = np.ascontiguousarray(other_img, dtype=np.uint8)
-                d_img = self._up("img", img, torch.uint8)
-                d_mw = self._up("mesh_w", mesh[0], torch.float64)
-                d_mh = self._up("mesh_h", mesh[1], torch.float64)
-                d_out = self._get("canvas", (fh, fw, 3), torch.uint8)
-                wb = lib.apap_warp_workspace_bytes(rows, cols, fw, fh)
-                d_ww = self._get("warp_work", (wb,), torch.uint8)
+                d_img = self._up("img", img, torch.uint8)       # blocks the host while the GPU solves
+                d_cen = None
                 if center_img is not None:
                     cen = np.ascontiguousarray(center_img, dtype=np.uint8)
                     d_cen = self._up("center", cen, torch.uint8)
-                    _native.check(lib.apap_stitch_device(self._h, d_img.data_ptr(), img.shape[0], img.shape[1], d_cen.data_ptr(),
-                                                         cen.shape[0], cen.shape[1], d_H.data_ptr(), rows, cols, d_mw.data_ptr(),
-                                                         mesh.shape[1], d_mh.data_ptr(), mesh.shape[1], fw, fh, ox, oy,
-                                                         d_out.data_ptr(), None, d_ww.data_ptr(), wb, d_status.data_ptr(), stream))
+                d_out = self._get("canvas", (fh, fw, 3), torch.uint8)
+                if plan is not None:
+                    plan.gather(d_img, out=d_out.view(1, fh, fw, 3), centers=d_cen)
                 else:
-                    _native.check(lib.apap_warp_device(self._h, d_img.data_ptr(), img.shape[0], img.shape[1], d_H.data_ptr(), rows,
-                                                       cols, d_mw.data_ptr(), mesh.shape[1], d_mh.data_ptr(), mesh.shape[1], fw, fh,
-                                                       ox, oy, d_out.data_ptr(), None, d_ww.data_ptr(), wb, d_status.data_ptr(),
-                                                       stream))
+                    d_mw = self._up("mesh_w", mesh[0], torch.float64)
+                    d_mh = self._up("mesh_h", mesh[1], torch.float64)
+                    wb = lib.apap_warp_workspace_bytes(rows, cols, fw, fh)
+                    d_ww = self._get("warp_work", (wb,), torch.uint8)
+                    _native.check(lib.apap_warp_batch_device(self._h, d_img.data_ptr(), 0, img.shape[0], img.shape[1],
+                                                             None if d_cen is None else d_cen.data_ptr(), 0,
+                                                             0 if d_cen is None else cen.shape[0], 0 if d_cen is None else cen.shape[1],
+                                                             d_H.data_ptr(), rows, cols, d_mw.data_ptr(), mesh.shape[1], d_mh.data_ptr(),
+                                                             mesh.shape[1], fw, fh, ox, oy, 0, fh, d_out.data_ptr(), 0, None, 1,
+                                                             _native.WARP_ALL, d_ww.data_ptr(), wb, d_status.data_ptr(), stream))
             t2 = time.perf_counter()
-            # the one trip back
-            flat = self._down(d_flat)                         # (synchronises the stream)
-            canvas = self._down(d_out) if d_out is not None else None
+            # the .mat array comes down on the side stream beside the warp kernel, the canvas after it
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(flat_ready)
+                flat = self._down(d_flat)
+            canvas = self._down(d_out) if d_out is not None else None          # (synchronises the main stream)
             status = int(d_status.cpu()[0])
             grid = self._down(d_H).reshape(rows, cols, 3, 3) if want_grid else None
         t3 = time.perf_counter()

@@ -841,6 +841,13 @@ def test_other_warp_kernel_forms_still_match(native, golden, rows_per_wave, fast
     p = config_pair("C2")
     w, _ = native.local_warp(p.img, g["H_ref"], p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=ctx)
     assert hashlib.sha256(w.tobytes()).digest() == g["warped_sha256"].tobytes()
+    # config 5's geometry: a 100 x 100 mesh over a 4K canvas (cells ~40 x 22 pixels: another cells-per-strip regime than C3's
+    # 20 x 11), pair 0 against the reference's canvas
+    g5, g5w = golden("c5_ref_k0"), golden("c5_warp_k0")
+    p5 = config_pair("C5")
+    w5, hinv5 = native.local_warp(p5.img, g5["H_ref"], p5.mesh[0], p5.mesh[1], p5.final_w, p5.final_h, p5.off_x, p5.off_y, ctx=ctx)
+    assert hashlib.sha256(w5.tobytes()).digest() == g5w["warped_sha256"].tobytes()
+    assert hashlib.sha256(hinv5.tobytes()).digest() == g5w["Hinv_sha256"].tobytes()
     ctx.close()
 
 
@@ -895,8 +902,25 @@ def test_fast_warp_on_irregular_meshes_and_strong_perspective(native, seed):
         exact_ctx.close()
     assert np.array_equal(hinv_f, hinv_e)
     assert np.array_equal(out_f, out_e)
-    if np.array_equal(hinv_f, hinv_ref):         # (nearly singular random cells may differ from numpy's inverse by an ulp)
+    # against the oracle, ALWAYS: its pixel rules on the inverses the engine wrote back ...
+    assert np.array_equal(out_f, O.local_warp_fast(img, hinv_f, (mesh_w, mesh_h), (fw, fh), (ox, oy)))
+    # ... and on numpy's own inverses wherever the two agree bit for bit (a nearly singular random cell may differ from
+    # numpy's inverse by one float32 ulp: counted, test_fast_warp_seeds_that_equal_numpy_s_inverses asserts >= 8 of 12)
+    assert ulp_diff_f32(hinv_f, hinv_ref).max() <= 1 or not np.isfinite(hinv_ref).all()
+    _INVERSE_EQUAL[seed] = bool(np.array_equal(hinv_f, hinv_ref))
+    if _INVERSE_EQUAL[seed]:
         assert np.array_equal(out_f, ref)
+
+
+_INVERSE_EQUAL = {}
+
+
+def test_fast_warp_seeds_that_equal_numpy_s_inverses(native):
+    """Of the 12 irregular-mesh seeds above, how many had inverses bit-identical to numpy.linalg.inv's (and were therefore
+    compared with the oracle on numpy's inverses as well): at least 8 (run after the parametrised test, same process)."""
+    if len(_INVERSE_EQUAL) < 12:
+        pytest.skip("needs the 12 seeds of test_fast_warp_on_irregular_meshes_and_strong_perspective in this process")
+    assert sum(_INVERSE_EQUAL.values()) >= 8, _INVERSE_EQUAL
 
 
 def test_overlapped_host_warp_equals_sequential(native, golden):
@@ -937,6 +961,66 @@ def test_overlapped_host_warp_equals_sequential(native, golden):
         b1, _ = native.local_warp(img, Hrot, mesh_w, bad_h, fw, fh, 0, 0, ctx=ovl)
         b0, _ = native.local_warp(img, Hrot, mesh_w, bad_h, fw, fh, 0, 0)
         assert np.array_equal(b0, b1)
+    finally:
+        ovl.close()
+
+
+def test_overlapped_host_warp_on_buffers_that_share_pages(native, golden):
+    """Round 3 saw one GPU fault ("write access to a read-only page") with the grid and its inverse pinned next to each other;
+    tools/hostreg_pages.hip (profiles/r04_hostreg_pages.txt) runs that layout - two registrations sharing a page, DMA and
+    kernel access, either unregistration order - without a fault, so the cause was not the shared page; the call still pins
+    only page-disjoint big buffers.  Here every buffer of the call is a view of ONE allocation, neighbours 16 bytes apart
+    (source image, canvas, centre image, the grid and the array its inverses are written back to - numpy's H.copy() followed by
+    np.empty_like(H) - and the edges): with APAP_OPT_OVERLAP_PCIE = 1 the canvas and the inverses must equal the sequential
+    call's, byte for byte; and a layout whose big buffers ARE page-disjoint (the pinned, banded path) with the small ones
+    packed against them."""
+    import ctypes as C
+    g = golden("c2_ref")
+    p = config_pair("C2")
+    H = np.ascontiguousarray(g["H_ref"], dtype=np.float32)
+    center = np.random.default_rng(4).integers(0, 256, p.shape, dtype=np.uint8)
+    ref, hinv_ref = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    sref, _ = native.local_stitch(p.img, center, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    nb = {"img": p.img.nbytes, "out": ref.nbytes, "center": center.nbytes, "H": H.nbytes, "Hinv": H.nbytes, "mw": p.mesh[0].nbytes,
+          "mh": p.mesh[1].nbytes}
+    ovl = native.Context(overlap_pcie=1)
+    try:
+        for page_disjoint in (False, True):
+            block = np.zeros(sum(nb.values()) + 7 * 16 + 8 * 4096 + 64, dtype=np.uint8)
+            base = block.ctypes.data
+            off = (-base) % 16 + 16
+            views = {}
+            for name in ("H", "Hinv", "img", "mw", "out", "mh", "center"):
+                if page_disjoint and name in ("img", "out", "center"):
+                    off += (-(base + off)) % 4096             # a page of its own ...
+                views[name] = block[off:off + nb[name]]
+                off += nb[name]
+                if page_disjoint and name in ("img", "out", "center"):
+                    off += (-(base + off)) % 4096             # ... to its end
+                off += 16 - off % 16 if off % 16 else 16      # what malloc leaves between two chunks
+            views["img"][:] = p.img.reshape(-1)
+            views["center"][:] = center.reshape(-1)
+            views["H"][:] = H.view(np.uint8).reshape(-1)
+            views["mw"][:] = p.mesh[0].view(np.uint8)
+            views["mh"][:] = p.mesh[1].view(np.uint8)
+            ptr = lambda name, t: C.cast(views[name].ctypes.data, C.POINTER(t))     # noqa: E731
+            for stitch in (False, True):
+                views["out"][:] = 0
+                views["Hinv"][:] = 0
+                if stitch:
+                    rc = native.lib().apap_local_stitch(ovl.handle, ptr("img", C.c_uint8), p.shape[0], p.shape[1], ptr("center", C.c_uint8),
+                                                        p.shape[0], p.shape[1], ptr("H", C.c_float), 100, 100, ptr("mw", C.c_double), 101,
+                                                        ptr("mh", C.c_double), 101, p.final_w, p.final_h, p.off_x, p.off_y,
+                                                        ptr("out", C.c_uint8), ptr("Hinv", C.c_float), -1)
+                else:
+                    rc = native.lib().apap_local_warp(ovl.handle, ptr("img", C.c_uint8), p.shape[0], p.shape[1], ptr("H", C.c_float), 100, 100,
+                                                      ptr("mw", C.c_double), 101, ptr("mh", C.c_double), 101, p.final_w, p.final_h, p.off_x,
+                                                      p.off_y, ptr("out", C.c_uint8), ptr("Hinv", C.c_float), -1)
+                assert rc == 0, native.last_error()
+                assert np.array_equal(views["out"].reshape(ref.shape), sref if stitch else ref), (page_disjoint, stitch)
+                assert np.array_equal(views["Hinv"].view(np.float32).reshape(hinv_ref.shape), hinv_ref), (page_disjoint, stitch)
+                assert np.array_equal(views["H"].view(np.float32).reshape(H.shape), H)         # the inputs are untouched
+                assert np.array_equal(views["img"].reshape(p.img.shape), p.img)
     finally:
         ovl.close()
 
