@@ -385,7 +385,10 @@ def cpu_baseline(cfg, budget_cells, budget_rows, pool_workers, default_threads_b
         "value": len(cells) / t_solve, "unit": "homographies/s", "cores": 1, "kind": "port",
         "sample": f"{len(cells)} of {rows * cols} cells (seeded random), {len(sub)} of {p.final_h} canvas rows + all "
                   f"{rows * cols} cell inversions; oracle faithful-loop numpy port, OPENBLAS_NUM_THREADS=1, "
-                  f"host has {os.cpu_count()} logical cores, {usable_cores()} usable by this process",
+                  f"host has {os.cpu_count()} logical cores, {usable_cores()} usable by this process; two liberties of the port, both "
+                  f"in the CPU's favour: the two 3 x 3 inverses the reference recomputes in every cell (apap.py:164-165) are taken "
+                  f"once per pair, and point_normalize / matrix_generate (apap.py:92-119, Python loops over the keypoints in the "
+                  f"reference) are vectorised",
         "warp_value": len(sub) * p.final_w / t_warp / 1e6, "warp_unit": "Mpix/s",
         "solve_s": t_solve, "warp_s": t_warp,
         "default_blas_threads": default_threads,
