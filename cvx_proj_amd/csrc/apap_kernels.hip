@@ -1456,10 +1456,24 @@ __device__ __forceinline__ void cswap(bool c, double &x, double &y) {
     y = ty;
 }
 
-__device__ __forceinline__ bool inv3(const double *m, double *out) {
+// a / b with 1 / b in hand (rb = rcp_full(b)): the product and one residual correction - the Markstein sequence, which
+// returns the correctly rounded quotient except in a vanishing share of cases (then 1 ulp off); `plain` false (a pivot that
+// is zero, denormal, huge or NaN): the IEEE division.  Twelve of these replace twelve ~30-instruction division sequences in
+// inv3, which runs once per cell in the solve's tail and in the warp's set-up.
+template <bool kFast>
+__device__ __forceinline__ double quot(double a, double b, double rb) {
+    if (!kFast) return a / b;
+    const double q0 = a * rb;
+    return fma(fma(-b, q0, a), rb, q0);
+}
+
+// `plain` (kFast only): every pivot was an ordinary number - the reciprocal-based quotients are valid
+template <bool kFast>
+__device__ __forceinline__ bool inv3_impl(const double *m, double *out, bool &plain) {
     double a00 = m[0], a01 = m[1], a02 = m[2], a10 = m[3], a11 = m[4], a12 = m[5], a20 = m[6], a21 = m[7], a22 = m[8];
     double b00 = 1, b01 = 0, b02 = 0, b10 = 0, b11 = 1, b12 = 0, b20 = 0, b21 = 0, b22 = 1;
-    bool ok = true;
+    bool ok = true, p0, p1;
+    double r0, r1;
     // column 0 pivot: first maximal |a_i0|
     {
         const bool s1 = fabs(a10) > fabs(a00);
@@ -1472,7 +1486,9 @@ __device__ __forceinline__ bool inv3(const double *m, double *out) {
         // non-pivot rows differently from LAPACK; the inverse does not depend on it
         // beyond rounding at the 1e-16 level.
         ok = ok && (a00 != 0.0);
-        const double l1 = a10 / a00, l2 = a20 / a00;
+        p0 = fabs(a00) >= 1e-290 && fabs(a00) <= 1e290;
+        r0 = kFast ? rcp_full(a00) : 0.0;
+        const double l1 = quot<kFast>(a10, a00, r0), l2 = quot<kFast>(a20, a00, r0);
         a11 = fma(-l1, a01, a11); a12 = fma(-l1, a02, a12);
         b10 = fma(-l1, b00, b10); b11 = fma(-l1, b01, b11); b12 = fma(-l1, b02, b12);
         a21 = fma(-l2, a01, a21); a22 = fma(-l2, a02, a22);
@@ -1483,20 +1499,43 @@ __device__ __forceinline__ bool inv3(const double *m, double *out) {
         cswap(s, a11, a21); cswap(s, a12, a22);
         cswap(s, b10, b20); cswap(s, b11, b21); cswap(s, b12, b22);
         ok = ok && (a11 != 0.0);
-        const double l = a21 / a11;
+        p1 = fabs(a11) >= 1e-290 && fabs(a11) <= 1e290;
+        r1 = kFast ? rcp_full(a11) : 0.0;
+        const double l = quot<kFast>(a21, a11, r1);
         a22 = fma(-l, a12, a22);
         b20 = fma(-l, b10, b20); b21 = fma(-l, b11, b21); b22 = fma(-l, b12, b22);
     }
     ok = ok && (a22 != 0.0);
+    const bool p2 = fabs(a22) >= 1e-290 && fabs(a22) <= 1e290;
+    const double r2 = kFast ? rcp_full(a22) : 0.0;
+    plain = p0 && p1 && p2;
     // back substitution, column by column
-    const double x20 = b20 / a22, x21 = b21 / a22, x22 = b22 / a22;
-    const double x10 = fma(-a12, x20, b10) / a11, x11 = fma(-a12, x21, b11) / a11, x12 = fma(-a12, x22, b12) / a11;
-    const double x00 = fma(-a02, x20, fma(-a01, x10, b00)) / a00;
-    const double x01 = fma(-a02, x21, fma(-a01, x11, b01)) / a00;
-    const double x02 = fma(-a02, x22, fma(-a01, x12, b02)) / a00;
+    const double x20 = quot<kFast>(b20, a22, r2), x21 = quot<kFast>(b21, a22, r2), x22 = quot<kFast>(b22, a22, r2);
+    const double x10 = quot<kFast>(fma(-a12, x20, b10), a11, r1), x11 = quot<kFast>(fma(-a12, x21, b11), a11, r1),
+                 x12 = quot<kFast>(fma(-a12, x22, b12), a11, r1);
+    const double x00 = quot<kFast>(fma(-a02, x20, fma(-a01, x10, b00)), a00, r0);
+    const double x01 = quot<kFast>(fma(-a02, x21, fma(-a01, x11, b01)), a00, r0);
+    const double x02 = quot<kFast>(fma(-a02, x22, fma(-a01, x12, b02)), a00, r0);
     out[0] = x00; out[1] = x01; out[2] = x02;
     out[3] = x10; out[4] = x11; out[5] = x12;
     out[6] = x20; out[7] = x21; out[8] = x22;
+    return ok;
+}
+
+// 3 x 3 inverse by LU with partial pivoting (what numpy.linalg.inv does in float64, apap.py:203).  The common path takes its
+// twelve quotients from three reciprocals; a wave that holds a cell with a zero, denormal, huge or NaN pivot redoes its cells
+// with IEEE divisions (wave-uniform branch).
+__device__ __forceinline__ bool inv3(const double *m, double *out) {
+    bool plain;
+    bool ok = inv3_impl<true>(m, out, plain);
+    if (!__all(plain)) {
+        double o2[9];
+        bool dummy;
+        const bool ok2 = inv3_impl<false>(m, o2, dummy);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = plain ? out[k] : o2[k];
+        ok = plain ? ok : ok2;
+    }
     return ok;
 }
 
@@ -2343,7 +2382,11 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
         unsigned thr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#ifdef APAP_K3_ABL_ONECELL     // experiment (wrong pixels where a lane straddles two cells): fewer registers -> more waves per SIMD?
+            const bool is_a = true;
+#else
             const bool is_a = (k == 0) || (k != 3 && col[k] == col[0]);
+#endif
             const float4 q0 = is_a ? a0 : b0, q1 = is_a ? a1 : b1, q2 = is_a ? a2 : b2;
             nx0[k] = __builtin_fmaf(q0.x, dxf[k], q0.z);
             ny0[k] = __builtin_fmaf(q0.w, dxf[k], q1.y);
