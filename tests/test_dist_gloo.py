@@ -264,3 +264,34 @@ def test_hip_solve_refuses_cpu_tensors():
     with pytest.raises(_native.ApapError):
         hip_solve(torch.zeros((4, 32), dtype=torch.float64), torch.zeros(36, dtype=torch.float64),
                   torch.zeros((2, 2), dtype=torch.float64), 0.5, 100.0)
+
+
+def test_same_bits_leaves_the_caller_s_context_alone_and_short_meshes_keep_unaligned_bands():
+    """ShardedSolver(same_bits=True) pins APAP_OPT_PLAN_CELLS on a context of its OWN (the caller's keeps planning from its
+    own calls); bands are aligned to the mesh rows only when the row edges reach the canvas's last row (edges that stop short must
+    keep the index error of the single-GPU path, apap.py:207) - ADVICE r3."""
+    from cvx_proj_amd import _native
+    from cvx_proj_amd.dist import ShardedSolver, hip_solve
+    from cvx_proj_amd.synth import synth_pair
+    p = synth_pair(320, 240, 60, 6, seed=9, with_image=False)
+    ctx = _native.Context(careful=0)
+    try:
+        s = ShardedSolver(p, torch.device("cpu"), None, solve_fn=hip_solve, ctx=ctx, same_bits=True)
+        assert ctx.get("plan_cells") == 0 and ctx.get("careful") == 0
+        assert s._ctx is not ctx and s._ctx.get("plan_cells") == 36 and s._ctx.get("careful") == 0
+    finally:
+        ctx.close()
+
+    class FakeDist:
+        def get_rank(self): return 1
+        def get_world_size(self): return 2
+        def broadcast(self, t, src=0): pass
+    for short in (False, True):
+        q = synth_pair(320, 240, 60, 6, seed=9)
+        if short:
+            q.mesh = q.mesh.copy()
+            q.mesh[1, -1] = q.final_h - 5.0        # the last row edge stops 5 rows short of the canvas
+        s = ShardedSolver(q, torch.device("cpu"), FakeDist(), solve_fn=oracle_solve, warp_fn=oracle_warp_rows)
+        s._warp_setup()
+        assert s._aligned == (not short)
+        assert s.bands[0][0] == 0 and s.bands[-1][1] == q.final_h

@@ -104,3 +104,20 @@ def test_checksum_of_c2_through_the_lazy_object(native, golden):
     assert np.allclose(W[0, 0], g["W_row0"], rtol=1e-14) and np.allclose(W[-1, -1], g["W_last"], rtol=1e-14)
     assert W._full is None
     assert np.allclose([W.sum(), (W * W).sum()], g["W_checksum"], rtol=1e-13)
+
+
+def test_assignment_materialises_and_truthy_flags_return_the_lazy_object(lazy, monkeypatch):
+    """A caller ported from the reference may write into the weights (``W[i, j] = ...``) or pass a truthy ``return_weights``
+    that is not literally ``True`` (``1``, ``np.True_``): the first gets the real array from then on, the second the lazy
+    object - not ``None``."""
+    W, full, calls = lazy
+    W[2, 3] = 0.25
+    assert W._full is not None and np.all(W[2, 3] == 0.25) and np.array_equal(W[1], full[1])
+    monkeypatch.setattr(_native, "local_homography", lambda *a, **k: (np.zeros((2, 2, 3, 3), np.float32), None))
+    eng = APAP(0.5, 10.0, [4, 4], [0, 0])
+    src = np.zeros((5, 2), np.float32)
+    verts = np.zeros((2, 2, 2))
+    for flag in (True, 1, np.True_):
+        assert isinstance(eng.local_homography(src, src, verts, return_weights=flag)[1], LazyWeights)
+    for flag in (False, 0, None):
+        assert eng.local_homography(src, src, verts, return_weights=flag)[1] is None
