@@ -232,3 +232,59 @@ def test_fuzz_ransac(native, seed):
         # the re-fit is the hot path on the inliers: float32-exact except for nearly
         # degenerate inlier sets (same caveat as the path's own fuzz cases)
         assert np.allclose(H, H_ref, rtol=1e-5, atol=1e-7), np.abs(H - H_ref).max()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_fuzz_resident_forms(native, seed):
+    """The forms round 4 added, on the random cases above (any mesh shape, 5 ... 2500 keypoints, gamma = 0 included, strong
+    perspective, singular or non-finite cells replaced as in test_fuzz_solve_and_warp): the solve whose tail leaves the cells
+    warp ready gives the plain solve's grid and the set-up kernel's workspace bytes; the gather on it - strips and column walk,
+    a batch of two pairs, a row band - gives the host-buffer call's canvas (itself checked against the oracle above)."""
+    import torch
+    from cvx_proj_amd.dist import WarpPlan, hip_solve_batch
+    dev = torch.device("cuda:0")
+    c = random_case(1000 + seed)
+    rows, cols = c["shape"]
+    fw, fh = c["canvas"]
+    ox, oy = c["off"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)     # noqa: E731
+    q = native.host_prepare(c["src"], c["dst"])
+    table = t(native.host_build_table(c["src"], q["cf1"], q["cf2"]))
+    den = t(native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"]))
+    vert = t(c["verts"].reshape(-1, 2))
+    H_host, _ = native.local_homography(c["src"], c["dst"], c["verts"], c["gamma"], c["sigma"], want_weights=False)
+    tables, dens = torch.stack([table, table]), torch.stack([den, den])
+    imgs = torch.stack([t(c["img"]), t(np.ascontiguousarray(c["img"][::-1]))])
+    plan = WarpPlan(c["mesh"], (rows, cols), fw, fh, ox, oy, dev, batch=2)
+    other = WarpPlan(c["mesh"], (rows, cols), fw, fh, ox, oy, dev, batch=2)
+    H = plan.solve(tables, dens, vert, c["gamma"], c["sigma"])
+    H_plain = hip_solve_batch(tables, dens, vert, c["gamma"], c["sigma"]).view(-1, 9)
+    assert torch.equal(H.view(torch.int32), H_plain.view(torch.int32))               # bit for bit, NaN cells included
+    assert np.array_equal(H[:rows * cols].cpu().numpy().reshape(rows, cols, 3, 3).view(np.int32), H_host.view(np.int32))
+    other.cells(H_plain)
+    torch.cuda.synchronize()
+    assert torch.equal(plan.work, other.work)
+    assert int(plan.status.cpu()[0]) == int(other.status.cpu()[0])
+    # the warp on a usable grid (the reference raises on singular cells: replaced by the identity, like above)
+    Hn = H_host.copy()
+    ok = np.isfinite(Hn).all(axis=(2, 3))
+    Hn[~ok] = np.eye(3, dtype=np.float32)
+    dets = np.linalg.det(Hn.astype(np.float64))
+    Hn[np.abs(dets) <= 1e-12] = np.eye(3, dtype=np.float32)
+    want0, _ = native.local_warp(c["img"], Hn, c["mesh"][0], c["mesh"][1], fw, fh, ox, oy)
+    want1, _ = native.local_warp(np.ascontiguousarray(c["img"][::-1]), Hn, c["mesh"][0], c["mesh"][1], fw, fh, ox, oy)
+    Hd = t(np.stack([Hn, Hn]).reshape(-1, 9))
+    walk = native.Context(warp_walk=1, warp_stage=1 + seed % 2)
+    try:
+        for ctx in (None, walk):
+            p2 = WarpPlan(c["mesh"], (rows, cols), fw, fh, ox, oy, dev, batch=2, ctx=ctx)
+            p2.cells(Hd)
+            out = p2.gather(imgs)
+            assert np.array_equal(out[0].cpu().numpy(), want0) and np.array_equal(out[1].cpu().numpy(), want1), ctx is walk
+            a, n = fh // 3, max(1, fh // 2)
+            n = min(n, fh - a)
+            band = p2.gather(imgs, rows=(a, n))
+            assert torch.equal(band, out[:, a:a + n])
+            assert int(p2.status.cpu()[0]) == 0
+    finally:
+        walk.close()
