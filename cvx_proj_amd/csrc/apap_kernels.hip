@@ -2620,43 +2620,13 @@ __device__ __forceinline__ void walk_store_row(const WalkGeo &a, const uint8_t *
     }
 }
 
-typedef int walk_rsrc_t __attribute__((ext_vector_type(4)));
-
-// One source pixel's dword through the image's buffer descriptor, hidden from hipcc's wait counting (with a set of gathers
-// carried around the loop hipcc drains the queue where the set is only issued): the destination is not valid until
-// walk_wait() below names it.
-#ifndef APAP_WALK_ASM
-#define APAP_WALK_ASM 0      // 1: the gathers as inline asm with a hand-placed wait (measured 2.5x SLOWER than the loads hipcc counts)
-#endif
-#ifndef APAP_WALK_NOP
-#define APAP_WALK_NOP "s_nop 0"
-#endif
-__device__ __forceinline__ unsigned walk_gather(unsigned off, walk_rsrc_t rsrc, __amdgpu_buffer_rsrc_t rs) {
-#if APAP_WALK_ASM
-    unsigned v;
-    asm volatile(APAP_WALK_NOP "\n\tbuffer_load_dword %0, %1, %2, 0 offen\n\ts_nop 0" : "=v"(v) : "v"(off), "s"(rsrc));
-    return v;
-#else
+// One source pixel's dword through the image's buffer descriptor (a load hipcc counts: with ONE set of gathers carried around
+// the loop its own counted waits are right - it waits for the set where the set is used.  Two forms that were tried and dropped:
+// two sets in flight, where hipcc's wait counting across the back edge drains the queue early; and the gathers as inline asm with a
+// hand-placed s_waitcnt, which ran 2.5 x slower than this builtin with an identical instruction stream -
+// profiles/r04_k3_experiments.txt).
+__device__ __forceinline__ unsigned walk_gather(unsigned off, __amdgpu_buffer_rsrc_t rs) {
     return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
-#endif
-}
-
-// Everything issued so far has landed, the set `px` in particular.
-template <int S>
-__device__ __forceinline__ void walk_wait(unsigned (&px)[S][4]) {
-#if APAP_WALK_ASM
-    if constexpr (S == 1)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]));
-    else if constexpr (S == 2)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]), "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]),
-                       "+v"(px[1][3]));
-    else
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(px[0][0]), "+v"(px[0][1]), "+v"(px[0][2]), "+v"(px[0][3]), "+v"(px[1][0]), "+v"(px[1][1]), "+v"(px[1][2]),
-                       "+v"(px[1][3]), "+v"(px[2][0]), "+v"(px[2][1]), "+v"(px[2][2]), "+v"(px[2][3]), "+v"(px[3][0]), "+v"(px[3][1]),
-                       "+v"(px[3][2]), "+v"(px[3][3]));
-#endif
 }
 
 // the float32 estimate of one pixel (k_warp_fast's arithmetic): source byte offset or the "outside" marker, and whether the
@@ -2721,12 +2691,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const float4 *__restrict__ fexact = fexact_all + (long long)pair * a.st.frec;
         // the image as a buffer: offsets at or beyond img_bytes (the "outside" marker) read as 0
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), (short)0, (int)img_bytes, 0x00020000);
-        walk_rsrc_t rsv, rsrc;
-        __builtin_memcpy(&rsv, &rs, 16);
-        rsrc.x = __builtin_amdgcn_readfirstlane(rsv.x);       // the asm operand must be four scalar registers
-        rsrc.y = __builtin_amdgcn_readfirstlane(rsv.y);
-        rsrc.z = __builtin_amdgcn_readfirstlane(rsv.z);
-        rsrc.w = __builtin_amdgcn_readfirstlane(rsv.w);
         // the last pixel's three bytes: the dword one byte earlier, shifted (no byte beyond the image is touched)
         unsigned last_px;
         __builtin_memcpy(&last_px, img + (img_bytes - 4u), 4);
@@ -2836,7 +2800,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 }
             }
             if (y_prev >= 0) {
-                walk_wait<S>(px);
                 const bool patched = __builtin_amdgcn_ballot_w64(patch != 0u) != 0;
 #pragma unroll
                 for (int t = 0; t < S; ++t) {
@@ -2855,7 +2818,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #pragma unroll
             for (int t = 0; t < S; ++t)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) px[t][k] = walk_gather(off[t][k], rsrc, rs);
+                for (int k = 0; k < 4; ++k) px[t][k] = walk_gather(off[t][k], rs);
             patch = patch_new;
             y_prev = y_new;
         }
