@@ -48,6 +48,7 @@ class Pipeline:
         self._buf = {}              # name -> device tensor, grown on demand and reused between pairs
         self.timeline = {}          # milliseconds of the last run_pair, by stage (host clock, after the final sync)
         self._plans = {}            # canvas geometry -> WarpPlan (lookup tables built once per geometry)
+        self._pinned = []           # page-locked host buffers handed out by pinned_array()
         self._side = torch.cuda.Stream(self.dev)          # download of the .mat array beside the warp
 
     # ------------------------------------------------------------------ device memory
@@ -75,6 +76,23 @@ class Pipeline:
 
     def _stream(self):
         return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def pinned_array(self, shape, dtype=np.uint8):
+        """A numpy array in page-locked host memory (owned by this pipeline).  A caller that reads its images INTO such arrays
+        (``np.copyto(buf, cv.imread(...))``, or a decoder writing in place) and passes them to ``run_pair`` gets asynchronous
+        copies: the image goes up beside the host set-up and the solve instead of after them, and ``canvas_out=`` receives
+        the canvas without the pin-and-copy detour of pageable memory.  Ordinary numpy arrays work as before."""
+        torch = self.torch
+        t = torch.empty(tuple(shape), dtype={np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32,
+                                             np.dtype(np.float64): torch.float64}[np.dtype(dtype)], pin_memory=True)
+        self._pinned.append(t)
+        return t.numpy()
+
+    def _is_pinned(self, a):
+        try:
+            return isinstance(a, np.ndarray) and a.flags.c_contiguous and a.dtype == np.uint8 and self.torch.from_numpy(a).is_pinned()
+        except (TypeError, ValueError, RuntimeError):
+            return False
 
     # ------------------------------------------------------------------ stages
     def equalize(self, img, name="eq", fetch=False):
@@ -113,7 +131,7 @@ class Pipeline:
         return plan
 
     def run_pair(self, src, dst, H_global, other_shape, center_shape, mesh_size=100, gamma=0.5, sigma=100,
-                 other_img=None, center_img=None, want_grid=False):
+                 other_img=None, center_img=None, want_grid=False, canvas_out=None):
         """Body of the reference's ``__main__`` between loading and saving (apap.py:238-264): returns
         ``(H_flat (m*m, 9) float64, canvas or None)`` (and the float32 H grid with ``want_grid``); the canvas is
         the warped other image or, with ``center_img``, the blended stitch of apap.py:258-262.
@@ -127,6 +145,19 @@ class Pipeline:
         import time
         torch, lib = self.torch, _native.lib()
         t0 = time.perf_counter()
+        early = None
+        if other_img is not None and self._is_pinned(other_img) and (center_img is None or self._is_pinned(center_img)):
+            # page-locked images: truly asynchronous copies, started before anything else on the side stream
+            with torch.cuda.device(self.dev), torch.cuda.stream(self._side):
+                d_img = self._get("img", other_img.shape, torch.uint8)
+                d_img.copy_(torch.from_numpy(other_img), non_blocking=True)
+                d_cen = None
+                if center_img is not None:
+                    d_cen = self._get("center", center_img.shape, torch.uint8)
+                    d_cen.copy_(torch.from_numpy(center_img), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            early = (d_img, d_cen, ev)
         fw, fh, ox, oy = (int(v) for v in final_size(_Shape(center_shape), _Shape(other_shape), H_global))
         mesh = get_mesh((fw, fh), mesh_size + 1)
         rows = cols = int(mesh_size)
@@ -173,11 +204,16 @@ class Pipeline:
             d_out = None
             if other_img is not None:
                 img = np.ascontiguousarray(other_img, dtype=np.uint8)
-                d_img = self._up("img", img, torch.uint8)       # blocks the host while the GPU solves
-                d_cen = None
-                if center_img is not None:
-                    cen = np.ascontiguousarray(center_img, dtype=np.uint8)
-                    d_cen = self._up("center", cen, torch.uint8)
+                if early is not None:
+                    d_img, d_cen, ev = early
+                    main.wait_event(ev)
+                    cen = center_img
+                else:
+                    d_img = self._up("img", img, torch.uint8)       # blocks the host while the GPU solves
+                    d_cen = None
+                    if center_img is not None:
+                        cen = np.ascontiguousarray(center_img, dtype=np.uint8)
+                        d_cen = self._up("center", cen, torch.uint8)
                 d_out = self._get("canvas", (fh, fw, 3), torch.uint8)
                 if plan is not None:
                     plan.gather(d_img, out=d_out.view(1, fh, fw, 3), centers=d_cen)
@@ -197,7 +233,14 @@ class Pipeline:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(flat_ready)
                 flat = self._down(d_flat)
-            canvas = self._down(d_out) if d_out is not None else None          # (synchronises the main stream)
+            if d_out is not None and canvas_out is not None:
+                if canvas_out.shape != (fh, fw, 3) or canvas_out.dtype != np.uint8 or not canvas_out.flags.c_contiguous:
+                    raise ValueError(f"canvas_out must be a contiguous uint8 array of shape {(fh, fw, 3)}")
+                torch.from_numpy(canvas_out).copy_(d_out, non_blocking=True)
+                main.synchronize()
+                canvas = canvas_out
+            else:
+                canvas = self._down(d_out) if d_out is not None else None      # (synchronises the main stream)
             status = int(d_status.cpu()[0])
             grid = self._down(d_H).reshape(rows, cols, 3, 3) if want_grid else None
         t3 = time.perf_counter()

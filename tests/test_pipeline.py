@@ -50,3 +50,27 @@ def test_equalise_stays_on_the_device_and_matches_the_host_call(native):
     d = pipe.equalize(img)
     assert d.is_cuda and np.array_equal(d.cpu().numpy(), native.equalize_hist(img))
     assert np.array_equal(pipe.equalize(img, fetch=True), native.equalize_hist(img))
+
+
+def test_page_locked_buffers_give_the_same_bytes(native, golden):
+    """Images read into Pipeline.pinned_array() buffers and a page-locked ``canvas_out`` take asynchronous copies; warp and
+    stitch must give the bytes of the pageable path, and the reference's canvas."""
+    from cvx_proj_amd.pipeline import Pipeline
+    p = config_pair("C2")
+    m = p.vertices.shape[0]
+    pipe = Pipeline()
+    center = np.random.default_rng(3).integers(0, 256, p.shape, dtype=np.uint8)
+    img_pin, cen_pin = pipe.pinned_array(p.img.shape), pipe.pinned_array(center.shape)
+    np.copyto(img_pin, p.img)
+    np.copyto(cen_pin, center)
+    out_pin = pipe.pinned_array((p.final_h, p.final_w, 3))
+    args = (p.src, p.dst, p.Hg, p.shape, p.shape, m, p.gamma, p.sigma)
+    for cen_a, cen_b in ((None, None), (center, cen_pin)):
+        flat_a, canvas_a = pipe.run_pair(*args, other_img=p.img, center_img=cen_a)
+        out_pin[:] = 0
+        flat_b, canvas_b = pipe.run_pair(*args, other_img=img_pin, center_img=cen_b, canvas_out=out_pin)
+        assert canvas_b is out_pin and np.array_equal(flat_a, flat_b) and np.array_equal(canvas_a, canvas_b)
+        if cen_a is None:
+            assert hashlib.sha256(canvas_b.tobytes()).digest() == golden("c2_ref")["warped_sha256"].tobytes()
+    with pytest.raises(ValueError):
+        pipe.run_pair(*args, other_img=img_pin, canvas_out=np.zeros((3, 3, 3), np.uint8))
