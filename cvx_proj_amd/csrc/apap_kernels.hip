@@ -19,6 +19,19 @@
 
 #include "apap_internal.h"
 
+#ifdef APAP_K3_TRACE     // diagnostic build (tools/k3_trace.py): per-wave time stamps inside k_warp_fast<false, 4>
+__device__ long long g_k3[16384 * 8];
+#define APAP_K3_STAMP(i)                                                                              \
+    do {                                                                                              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        if (k3_id < 16384u && lane == 0) g_k3[k3_id * 8 + (i)] = (long long)wall_clock64();           \
+    } while (0)
+extern "C" int apap_debug_k3_trace(long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3), sizeof(long long) * (size_t)count);
+}
+#else
+#define APAP_K3_STAMP(i) do { } while (0)
+#endif
 #ifdef APAP_TRACE_SMALL
 __device__ long long g_tq[16];
 #define APAP_STAMP(i) do { if (blockIdx.x == 3 && threadIdx.x == 0) g_tq[i] = clock64(); } while (0)
@@ -2306,8 +2319,11 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
 #ifndef APAP_K3_BUF
 #define APAP_K3_BUF 0
 #endif
+#ifndef APAP_K3_WAVES_ATTR
+#define APAP_K3_WAVES_ATTR
+#endif
 template <bool kBlend, int kRows>
-__global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
+__global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
                                                    const double *__restrict__ hinv_pad, int mesh_rows, int mesh_cols,
                                                    const int *__restrict__ lut, const float4 *__restrict__ frec,
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
@@ -2324,6 +2340,10 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef APAP_K3_TRACE
+    const unsigned k3_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (unsigned)wave;
+    APAP_K3_STAMP(0);
+#endif
     const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
     const int y_first = row_begin + ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * kRows;
     const int y_end = min(y_first + kRows, row_begin + row_count);
@@ -2350,6 +2370,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
         rr[t] = __builtin_amdgcn_readfirstlane(e.x);
         dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.y));
     }
+    APAP_K3_STAMP(1);       // column and row entries have arrived
     unsigned off[kRows][4];
     unsigned int px[kRows][4];
     unsigned long long doubt[kRows][4];    // lane masks (scalar registers)
@@ -2376,6 +2397,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
         const unsigned base = r * rec_stride;
         const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
         const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+        APAP_K3_STAMP(2);   // the records of this pass have arrived (the last pass's stamp stays)
         // per pixel: x-dependent parts of the three sums, the y coefficients, anchor, window
         float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
         int n0x[4], n0y[4];
@@ -2422,6 +2444,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
             }
         }
     }
+    APAP_K3_STAMP(3);       // offsets computed
     // pixels in doubt: the exact float64 sequence.  Only waves that hold one come here.
     {
         unsigned long long any = 0;
@@ -2488,6 +2511,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
 #pragma unroll
         for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
 #endif
+    APAP_K3_STAMP(4);       // exact path done (if taken), gathers issued AND landed
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const int y = y_first + t;
@@ -2526,6 +2550,7 @@ __global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ i
             }
         }
     }
+    APAP_K3_STAMP(5);       // stores issued and acknowledged
 }
 
 // K3, persistent column-walk form (round 4).  The strip kernel above gives every wave ONE strip and a chain of three
