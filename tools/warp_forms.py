@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--forms", default="strips;walk;walk,warp_stage=1;walk,warp_stage=4;walk,warp_waves=8;walk,warp_waves=12;walk,warp_waves=20")
     ap.add_argument("--stitch", action="store_true")
     ap.add_argument("--condition-s", type=float, default=0.25)
+    ap.add_argument("--rows", type=int, default=0, help="warp only the first N canvas rows (a band): how the time scales with the number of strips")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
@@ -62,14 +63,14 @@ def main():
             N.check(N.lib().apap_warp_batch_device(ctx.handle, imgs[i].data_ptr(), 0, p.shape[0], p.shape[1],
                                                    None if center is None else center.data_ptr(), 0, p.shape[0], p.shape[1],
                                                    H.data_ptr(), rows, cols, mw.data_ptr(), mw.numel(), mh.data_ptr(), mh.numel(),
-                                                   p.final_w, p.final_h, p.off_x, p.off_y, 0, p.final_h, outs[i].data_ptr(), 0, None, 1,
+                                                   p.final_w, p.final_h, p.off_x, p.off_y, 0, a.rows or p.final_h, outs[i].data_ptr(), 0, None, 1,
                                                    phases, work.data_ptr(), wb, st.data_ptr(), ctypes.c_void_p(stream)))
         launch(0, N.WARP_ALL)
         torch.cuda.synchronize()
         if ref is None:
             ref = outs[0].clone()
         assert torch.equal(outs[0], ref), f"{form}: canvas differs from the first form's"
-        res = {"config": a.config, "form": form}
+        res = {"config": a.config, "form": form, "rows": a.rows or p.final_h}
         for mode, n in (("warm", 1), ("cold", nsets)):
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < a.condition_s:       # sustained clocks
