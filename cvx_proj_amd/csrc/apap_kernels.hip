@@ -1122,7 +1122,23 @@ struct WarpEmit {
     int n_w, n_h, mesh_rows, mesh_cols, final_w, final_h, off_x, off_y;
     int *status;
 };
-__device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, const float (&Hf)[9]);
+// the four mesh edges around a cell, fetched by the solve's kernels BEFORE the eigen-solve (one wave per SIMD there: a load at
+// the very end of the tail would be a fully exposed round trip)
+struct CellEdges {
+    double w0, w1, h0, h1;
+};
+__device__ __forceinline__ CellEdges warp_emit_prefetch(const WarpEmit &we, int cell) {
+    CellEdges e = {0.0, 0.0, 0.0, 0.0};
+    if (we.hinv_pad && cell >= 0) {
+        const int c = min(cell, we.mesh_rows * we.mesh_cols - 1);
+        const int er = c / we.mesh_cols, ec = c - er * we.mesh_cols;
+        // (the same guards as fast_origin: a mesh with fewer edges than cells + 1 has no ordinary cells)
+        if (ec + 1 < we.n_w) { e.w0 = we.mesh_w[ec]; e.w1 = we.mesh_w[ec + 1]; }
+        if (er + 1 < we.n_h) { e.h0 = we.mesh_h[er]; e.h1 = we.mesh_h[er + 1]; }
+    }
+    return e;
+}
+__device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, const float (&Hf)[9], const CellEdges &edges);
 
 // The per-cell tail shared by K2 and the fused small-mesh kernel: from the 30 moment sums of a
 // cell to its float32 homography.  Lanes = cells; inactive lanes are simply not in the wave votes.
@@ -1131,7 +1147,7 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
                                                   int pick_rank, int careful, const double *__restrict__ table, int n,
                                                   double vx, double vy, double gamma, double inv_sigma,
                                                   float *__restrict__ out /* 9 floats, or nullptr */,
-                                                  const WarpEmit &we, int pair, int cell) {
+                                                  const WarpEmit &we, int pair, int cell, const CellEdges &edges) {
     // A^T W^2 A = [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]  (3x3 blocks)
     double a[45];
 #pragma unroll
@@ -1221,7 +1237,7 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
         for (int k = 0; k < 9; ++k) out[k] = hf[k] = (float)q[k];
         // the caller warps next: the cell's inverse, its float32-estimate record and exact-path floats, straight into the
         // warp's workspace (what k_warp_setup's per-cell half would compute from the stored grid: the same function)
-        if (we.hinv_pad) warp_emit_from_solve(we, pair, cell, hf);
+        if (we.hinv_pad) warp_emit_from_solve(we, pair, cell, hf, edges);
     }
 #ifdef APAP_TRACE_SMALL
     APAP_STAMP(4);
@@ -1250,6 +1266,7 @@ __global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const do
     vertices += (long long)blockIdx.z * bs.vertices;
     const int cell = blockIdx.x * kWave + threadIdx.x;
     const int cc = min(cell, cells - 1);
+    const CellEdges edges = warp_emit_prefetch(we, cell < cells ? cell : -1);
     double m[kMoments];
 #pragma unroll
     for (int j = 0; j < kMoments; ++j) m[j] = moments[(size_t)j * cells_pad + cc];
@@ -1259,7 +1276,7 @@ __global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const do
         for (int j = 0; j < kMoments; ++j) m[j] += slab[(size_t)j * cells_pad];
     }
     eigen_denorm_cell<kUseInverseIteration>(m, denorm, pick_rank, careful, table, n, vertices[2 * cc], vertices[2 * cc + 1],
-                                            gamma, inv_sigma, cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell);
+                                            gamma, inv_sigma, cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell, edges);
 }
 
 // --------------------------------------------------------------------------------
@@ -1430,8 +1447,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
     double m[kMoments];
 #pragma unroll
     for (int j = 0; j < kMoments; ++j) m[j] = tot[lane * kRow + j];
+    const CellEdges edges = warp_emit_prefetch(we, cell < cells ? cell : -1);
     eigen_denorm_cell<kUseInverseIteration>(m, s_denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
-                                            cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell);
+                                            cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell, edges);
 #ifdef APAP_TRACE_SMALL
     tr[4] = clock64();
     if (blockIdx.x == 3 && tid == 0)
@@ -1637,11 +1655,17 @@ constexpr int kFastMaxSpan = 254;   // dx, dy travel as bytes
 
 // anchor of cell index c along one axis: first pixel at or after its lower edge, and how many pixels
 // the cell spans (clamped to kFastMaxSpan); false when the edges do not describe an ordinary cell
+__device__ __forceinline__ bool fast_origin_of(double e0, double e1, bool have, int count, int &x0, int &span);
 __device__ __forceinline__ bool fast_origin(const double *__restrict__ edges, int n_e, int c, int count, int &x0, int &span) {
     x0 = 0;
     span = 1;
     if (c < 0 || c + 1 >= n_e) return false;
-    const double e0 = edges[c], e1 = edges[c + 1];
+    return fast_origin_of(edges[c], edges[c + 1], true, count, x0, span);
+}
+__device__ __forceinline__ bool fast_origin_of(double e0, double e1, bool have, int count, int &x0, int &span) {
+    x0 = 0;
+    span = 1;
+    if (!have) return false;
     if (!(e0 > -1.0) || !(e1 > e0) || !(e0 < 2147483000.0)) return false;   // NaN fails every test
     const double a = fmin(fmax(ceil(e0), 0.0), (double)count);
     const double b = fmin(fmax(ceil(e1), 0.0), (double)count);
@@ -1782,13 +1806,16 @@ template <typename T>
 __device__ __forceinline__ void warp_cell_tables(const double (&m)[9], int er, int ec, int mesh_cols, const double *__restrict__ mesh_w,
                                                  int n_w, const double *__restrict__ mesh_h, int n_h, int final_w, int final_h,
                                                  int off_x, int off_y, double *__restrict__ hinv_pad, T *__restrict__ hinv_dense,
-                                                 float4 *__restrict__ frec, float4 *__restrict__ fexact, int *status, int *src_rows) {
+                                                 float4 *__restrict__ frec, float4 *__restrict__ fexact, int *status, int *src_rows,
+                                                 const CellEdges *edges = nullptr) {
     const int cell = er * mesh_cols + ec;
     const size_t e = (size_t)er * (mesh_cols + 1) + ec;
     double r[9];
-    int x0, y0, sx, sy;      // the edge loads travel with the matrix loads
-    const bool okx = fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
-    const bool oky = fast_origin(mesh_h, n_h, er, final_h, y0, sy);
+    int x0, y0, sx, sy;      // the edge loads travel with the matrix loads (or were fetched earlier: the solve's tail)
+    const bool okx = edges ? fast_origin_of(edges->w0, edges->w1, ec >= 0 && ec + 1 < n_w, final_w, x0, sx)
+                           : fast_origin(mesh_w, n_w, ec, final_w, x0, sx);
+    const bool oky = edges ? fast_origin_of(edges->h0, edges->h1, er >= 0 && er + 1 < n_h, final_h, y0, sy)
+                           : fast_origin(mesh_h, n_h, er, final_h, y0, sy);
     if (!inv3(m, r)) atomicOr(status, apap::kStatusSingular);
     double2 *p = reinterpret_cast<double2 *>(hinv_pad + (size_t)cell * APAP_HINV_STRIDE);
     // the inverse rounded to the grid's dtype (what the reference stores back, apap.py:203),
@@ -1817,7 +1844,7 @@ __device__ __forceinline__ void warp_cell_tables(const double (&m)[9], int er, i
 }
 
 // the solve's tail (eigen_denorm_cell) leaves its cell warp ready; the last column / row also write the extra entries
-__device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, const float (&Hf)[9]) {
+__device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, const float (&Hf)[9], const CellEdges &edges) {
     double m[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) m[k] = (double)Hf[k];
@@ -1825,7 +1852,7 @@ __device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, con
     double *hinv_pad = we.hinv_pad + (long long)pair * we.hinv_stride;
     float4 *frec = we.frec + (long long)pair * we.frec_stride, *fexact = we.fexact + (long long)pair * we.frec_stride;
     warp_cell_tables<float>(m, er, ec, we.mesh_cols, we.mesh_w, we.n_w, we.mesh_h, we.n_h, we.final_w, we.final_h, we.off_x, we.off_y,
-                            hinv_pad, (float *)nullptr, frec, fexact, we.status, (int *)nullptr);
+                            hinv_pad, (float *)nullptr, frec, fexact, we.status, (int *)nullptr, &edges);
     const size_t stride = (size_t)we.mesh_cols + 1;
     if (ec == we.mesh_cols - 1) warp_extra_entry(frec, fexact, (size_t)er * stride + we.mesh_cols);
     if (er == we.mesh_rows - 1) {
