@@ -118,7 +118,7 @@ typedef struct apap_ctx apap_ctx;
 #define APAP_OPT_OVERLAP_PCIE 9    /* 0 (default): apap_local_warp / apap_local_stitch make one copy up, one kernel, one copy
                                       down.  1: they pin the caller's buffers for the call (hipHostRegister) and overlap the
                                       image upload, the warp (in row bands) and the canvas download on three streams.  For
-                                      callers that REUSE their image / canvas buffers: the first use of a buffer pays ~8 ms of
+                                      callers that REUSE their image / canvas buffers: the first uses of a buffer pay 8-26 ms of
                                       pinning and mapping (4K pair), every later call saves ~15 %                              */
 #define APAP_OPT_PLAN_CELLS 10      /* 0 (default): the solve picks its kernel (fused small-mesh launch or K1 + K2) and its
                                       keypoint splits from THIS call's cells x batch.  c > 0: as for ONE pair of c cells,
@@ -127,7 +127,8 @@ typedef struct apap_ctx apap_ctx;
                                       number of ranks, at the price of fewer, larger blocks per GPU                      */
 #define APAP_OPT_WARP_WALK 11       /* K3 form: 0 = one strip of APAP_OPT_WARP_ROWS rows per wave; 1 = the persistent column-walk kernel:
                                       a grid sized to the chip, every wave walks down a contiguous share of the canvas rows of one
-                                      256-pixel column block, software-pipelined (same canvas, byte for byte)                    */
+                                      256-pixel column block, software-pipelined (same canvas, byte for byte).  Default 0: measured
+                                      7-15 % slower than the strips on every BASELINE configuration (profiles/r04_k3_experiments.txt) */
 #define APAP_OPT_WARP_WAVES 12      /* tuning, column-walk form: resident waves per CU (a multiple of 4; default 16)              */
 #define APAP_OPT_WARP_STAGE 13      /* tuning, column-walk form: canvas rows per pipeline stage (1, 2; default 2)                   */
 #define APAP_OPT_WARP_MIN_RUN 14    /* tuning, column-walk form: small canvases get fewer waves so that a wave keeps at least this
