@@ -76,6 +76,8 @@ def test_bench_self_launch_reports_pairs_and_cells(native):
     assert d["pair_per_rank"]["world_size"] == 2 and d["pair_per_rank"]["value"] == d["value"]
     c5 = d["pairs"]                                                   # BASELINE config 5: pairs dealt over the ranks, batched
     assert c5["world_size"] == 2 and c5["scaling"] == "strong" and c5["pairs_per_rank"] == 3 and c5["value"] > 0
+    assert c5["warp"]["value"] > 0 and c5["warp"]["us_per_pair"] > 0          # the warp half of config 5, batched per rank
+    assert c5["whole_job"]["pairs_per_s"] > 0 and c5["whole_job"]["one_stream_ms_per_step"] > 0
     c = d["cells"]
     assert c["world_size"] == 2 and c["scaling"] == "strong" and c["backend"] == "gloo"
     assert c["rank0_cells"] == 50 * 100                               # half of the 100 x 100 mesh
