@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one bench.py configuration on the GPU box.
 #   tools/profile.sh <tag> [bench.py args...]
+# Pass --no-c5 for clean per-kernel averages of the headline configuration: the `pairs` object launches the same kernels over 64
+# pairs at once (k_warp_fast, k_assemble_mfma, k_eigen_denorm, k_warp_setup with grid.z = pair), and rocprofv3 averages by name.
 # Writes gpurun_out/prof_<tag>/{stats,pmc_*}; copy the summaries you want judged to profiles/.
 set -o pipefail
 TAG=$1; shift
