@@ -880,6 +880,11 @@ def main():
             assert int(pb.status.cpu()[0]) == 0, "device status word set by the batched warp"
         cells_c5 = CONFIGS["C5"][3] ** 2
         c5_pixels = (pb.pair.final_w * pb.pair.final_h) if pb is not None else 0
+        # algorithmic bytes of the rank's batched warp: 6 B per pixel inside the source, 3 B per blank one, summed over its canvases
+        c5_bytes = 0
+        if pb is not None:
+            nzp = int((pb.out.view(pb.batch, -1, 3).amax(dim=2) > 0).sum().cpu())
+            c5_bytes = 6 * nzp + 3 * (pb.batch * c5_pixels - nzp)
         if dist is not None:
             tt = torch.tensor([float(c5_pixels)], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -902,6 +907,12 @@ def main():
                            "ms_per_step": t_c5w / w_steps * 1e3, "us_per_pair": t_c5w / w_steps / max(len(mine), 1) * 1e6,
                            "steps": w_steps,
                            "geometry_kept_us_per_pair": t_c5g / w_steps / max(len(mine), 1) * 1e6,
+                           "roofline": {"kernels": "k_warp_setup + k_warp_fast over the rank's pairs (rank 0)", "bound": "hbm",
+                                        "achieved": c5_bytes / (t_c5g / w_steps) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": c5_bytes / (t_c5g / w_steps) / 1e9 / PEAK_HBM_GBS,
+                                        "note": "whole batched step (per-cell set-up launch + gather launch), wall clock: the steady "
+                                                "state of K3 - many generations of waves, the ~4.5 us of launch, first table trips and "
+                                                "last stores paid once for all the pairs"},
                            "note": "apap_warp_batch_device: one set-up launch over every pair's cells and one gather launch over "
                                    "every canvas of the rank's pairs (grid.z = pair), source images and canvases resident; the "
                                    "canvases of the first and last pair are checked against one apap_warp_device launch each; "
