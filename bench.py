@@ -526,17 +526,23 @@ def pipeline_level(cfg, reps=5):
         flat_a, canvas_a = pipe.run_pair(*args, other_img=p.img)
         flat_b, canvas_b = pipe.run_pair(*args, other_img=pin_img, canvas_out=pin_out)
         assert np.array_equal(flat_a, flat_b) and np.array_equal(canvas_a, canvas_b)
-        t_pinned = med(lambda: pipe.run_pair(*args, other_img=pin_img, canvas_out=pin_out), reps)
+        t_pinned = med(lambda: pipe.run_pair(*args, other_img=pin_img, canvas_out=pin_out), max(reps, 9))
+        pipe.trace = True
+        pipe.run_pair(*args, other_img=pin_img, canvas_out=pin_out)
+        marks = {k: round(v, 1) for k, v in pipe.device_marks}
+        pipe.trace = False
     return {"workload": cfg, "solve_to_mat_array_ms": t_solve * 1e3, "solve_warp_to_mat_array_and_canvas_ms": t_warp * 1e3,
             "chain_of_calls_solve_ms": c_solve * 1e3, "chain_of_calls_solve_warp_ms": c_warp * 1e3,
             "solve_warp_with_page_locked_image_and_canvas_ms": t_pinned * 1e3,
+            "page_locked_pass_device_marks_us": marks,
             "timeline_solve": tl_solve, "timeline_solve_warp": tl_warp,
             "note": "numpy in -> numpy out, everything between resident in HBM on one stream, one trip back "
                     "(cvx_proj_amd/pipeline.py); chain_of_calls = the mirror class call by call as apap.py:238-264 is written "
                     "(local_homography, local_warp with its own copy of the grid, invert_normalize_flatten); with the warp both "
                     "are bound by 25 MB up + 27 MB down over PCIe from pageable numpy arrays; with_page_locked = the same pass when the "
-                    "caller keeps its image and canvas in Pipeline.pinned_array() buffers (asynchronous copies: the upload runs beside the "
-                    "host set-up and the solve); never `value`"}
+                    "caller keeps its image and canvas in Pipeline.pinned_array() buffers (every copy of the pass page-locked and asynchronous: "
+                    "the image upload runs beside the host set-up, the small uploads and the solve; device_marks = HIP events at the "
+                    "stage boundaries of one such pass, microseconds from its first enqueue); never `value`"}
 
 
 # ------------------------------------------------------------------------------------ self-launch

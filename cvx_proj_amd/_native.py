@@ -272,20 +272,29 @@ def host_dlt_rows(cf1, cf2):
     return aa
 
 
-def host_build_table(src, cf1, cf2):
+def _out_f64(out, shape):
+    """``out`` as the function's result buffer (e.g. page-locked staging memory of the caller's), or a fresh array."""
+    if out is None:
+        return np.empty(shape, np.float64)
+    if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == tuple(shape) and out.flags.c_contiguous):
+        raise ValueError(f"out must be a contiguous float64 array of shape {tuple(shape)}")
+    return out
+
+
+def host_build_table(src, cf1, cf2, out=None):
     src = as_f32(src, (2,))
     cf1 = as_f32(cf1, (2,))
     cf2 = as_f32(cf2, (2,))
     n = src.shape[0]
-    table = np.empty((n, TABLE_STRIDE), np.float64)
+    table = _out_f64(out, (n, TABLE_STRIDE))
     check(lib().apap_host_build_table(_ptr(src, C.c_float), _ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n,
                                       _ptr(table, C.c_double)))
     return table
 
 
-def host_build_denorm(iC2, C1, iN2, N1):
+def host_build_denorm(iC2, C1, iN2, N1, out=None):
     mats = [as_f32(m, (3, 3)) for m in (iC2, C1, iN2, N1)]
-    out = np.empty(DENORM_DOUBLES, np.float64)
+    out = _out_f64(out, (DENORM_DOUBLES,))
     check(lib().apap_host_build_denorm(*[_ptr(m, C.c_float) for m in mats], _ptr(out, C.c_double)))
     return out
 
@@ -324,14 +333,19 @@ def local_weights(src, points, gamma, sigma, device=-1, ctx=None):
     return W
 
 
-def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=True, device=-1, ctx=None):
+def local_warp(img, H, mesh_w, mesh_h, final_w, final_h, off_x, off_y, want_inverse=True, device=-1, ctx=None, out=None):
+    """``out``: the caller's own (final_h, final_w, 3) uint8 canvas (e.g. page-locked memory, which the library then neither
+    registers nor stages) instead of a fresh array."""
     img = np.ascontiguousarray(img, dtype=np.uint8)
     img_h, img_w, ch = img.shape
     if ch != 3:
         raise ValueError(f"image must be (h, w, 3); got {img.shape}")
     mesh_w = np.ascontiguousarray(mesh_w, dtype=np.float64)
     mesh_h = np.ascontiguousarray(mesh_h, dtype=np.float64)
-    out = np.empty((final_h, final_w, 3), np.uint8)
+    if out is None:
+        out = np.empty((final_h, final_w, 3), np.uint8)
+    elif not (isinstance(out, np.ndarray) and out.shape == (final_h, final_w, 3) and out.dtype == np.uint8 and out.flags.c_contiguous):
+        raise ValueError(f"out must be a contiguous uint8 array of shape {(final_h, final_w, 3)}")
     if isinstance(H, np.ndarray) and H.dtype == np.float64:
         # the reference inverts and multiplies in the grid's own dtype (apap.py:201-203,210-213): a
         # float64 grid is not rounded to float32 on the way

@@ -231,6 +231,14 @@ namespace {
 struct PinGuard {       // hipHostRegister for the duration of a call
     void *p = nullptr;
     bool pin(const void *ptr, size_t bytes, unsigned flags = hipHostRegisterDefault) {
+        // memory the caller already page-locked (hipHostMalloc, torch's pin_memory, its own hipHostRegister): nothing to do,
+        // nothing to undo
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeHost) {
+            hipPointerAttribute_t last;
+            if (hipPointerGetAttributes(&last, (const char *)ptr + bytes - 1) == hipSuccess && last.type == hipMemoryTypeHost) return true;
+        }
+        (void)hipGetLastError();
         if (hipHostRegister(const_cast<void *>(ptr), bytes, flags) != hipSuccess) {
             (void)hipGetLastError();
             return false;

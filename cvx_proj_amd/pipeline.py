@@ -20,6 +20,7 @@ torch is used for device memory and the stream only.  No CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 
@@ -50,6 +51,8 @@ class Pipeline:
         self._plans = {}            # canvas geometry -> WarpPlan (lookup tables built once per geometry)
         self._pinned = []           # page-locked host buffers handed out by pinned_array()
         self._side = torch.cuda.Stream(self.dev)          # download of the .mat array beside the warp
+        self.trace = False          # True: HIP events at the stage boundaries of run_pair -> self.device_marks (us from the first enqueue)
+        self.device_marks = []
 
     # ------------------------------------------------------------------ device memory
     def _get(self, name, shape, dtype):
@@ -86,6 +89,13 @@ class Pipeline:
         t = torch.empty(tuple(shape), dtype={np.dtype(np.uint8): torch.uint8, np.dtype(np.float32): torch.float32,
                                              np.dtype(np.float64): torch.float64}[np.dtype(dtype)], pin_memory=True)
         self._pinned.append(t)
+        return t.numpy()
+
+    def _staging(self, n):
+        """`n` float64 of page-locked staging memory (one block, reused by every pass; a pass ends synchronised)."""
+        t = getattr(self, "_stage_t", None)
+        if t is None or t.numel() < n:
+            t = self._stage_t = self.torch.empty(max(n, 1 << 16), dtype=self.torch.float64, pin_memory=True)
         return t.numpy()
 
     def _is_pinned(self, a):
@@ -136,18 +146,26 @@ class Pipeline:
         ``(H_flat (m*m, 9) float64, canvas or None)`` (and the float32 H grid with ``want_grid``); the canvas is
         the warped other image or, with ``center_img``, the blended stitch of apap.py:258-262.
 
-        What overlaps (round 4): the solve is enqueued FIRST and the 25 MB source image (and the centre image) go up while it
-        runs (a copy from pageable memory blocks the host, not the GPU; a helper thread for the upload was measured: its copy and
-        the main thread's small uploads serialise in the runtime's pin-and-copy path and the set-up slows down under the GIL -
-        no gain); the solve's tail leaves every cell warp ready, so the warp is the gather kernel alone on tables whose
-        geometry half (and the mesh's vertices) were built when this canvas geometry was first seen; the ``.mat`` array comes
-        down on a side stream beside the warp; the canvas is the one copy left on the critical path."""
+        What overlaps (round 4): with ordinary numpy images the solve is enqueued FIRST and the 25 MB source image goes up while it
+        runs (a copy from pageable memory blocks the host, not the GPU; a helper thread for the upload was measured: no gain).
+        With the images in page-locked arrays (``pinned_array``) the image upload starts before anything else on the side stream
+        and the host set-up, the small uploads and the solve run beside it: every copy of such a pass is a page-locked one -
+        keypoint table and de-normalisation are built straight into a staging block, the ``.mat`` array and the status word come
+        down into staging - because ONE pageable copy on the side stream makes the small uploads of every later pass wait for
+        the whole image upload (measured: tools/torch_copy_overlap.py, profiles/r04_pipeline_overlap.txt; 1.33 -> 1.04 ms).
+        The solve's tail leaves every cell warp ready, so the warp is the gather kernel alone on tables whose geometry half
+        (and the mesh's vertices) were built when this canvas geometry was first seen; the canvas download is the one copy
+        left on the critical path (0.5 ms of the 1.04).  ``self.trace = True`` records HIP events at the stage boundaries
+        (``self.device_marks``)."""
         import time
         torch, lib = self.torch, _native.lib()
         t0 = time.perf_counter()
         early = None
-        if other_img is not None and self._is_pinned(other_img) and (center_img is None or self._is_pinned(center_img)):
-            # page-locked images: truly asynchronous copies, started before anything else on the side stream
+        trace = self.trace or "events" in os.environ.get("APAP_PIPE_EXP", "")
+        pinned_in = other_img is not None and self._is_pinned(other_img) and (center_img is None or self._is_pinned(center_img))
+
+        def start_image_upload():
+            # page-locked images: truly asynchronous copies on the side stream
             with torch.cuda.device(self.dev), torch.cuda.stream(self._side):
                 d_img = self._get("img", other_img.shape, torch.uint8)
                 d_img.copy_(torch.from_numpy(other_img), non_blocking=True)
@@ -157,7 +175,20 @@ class Pipeline:
                     d_cen.copy_(torch.from_numpy(center_img), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-            early = (d_img, d_cen, ev)
+            return (d_img, d_cen, ev)
+
+        marks = []
+
+        def mark(name, stream=None):
+            if trace:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream if stream is not None else torch.cuda.current_stream(self.dev))
+                marks.append((name, e))
+
+        mark("begin", self._side)
+        if pinned_in:
+            early = start_image_upload()
+            mark("image up (side)", self._side)
         fw, fh, ox, oy = (int(v) for v in final_size(_Shape(center_shape), _Shape(other_shape), H_global))
         mesh = get_mesh((fw, fh), mesh_size + 1)
         rows = cols = int(mesh_size)
@@ -168,15 +199,22 @@ class Pipeline:
                 plan = self._plan(mesh, rows, cols, fw, fh, ox, oy)     # lookup tables + vertices of this geometry: built once
         vertices = None if plan is not None and plan.vertices is not None else get_vertice((fw, fh), mesh_size, (ox, oy))
         q = _native.host_prepare(src, dst)                                  # apap.py:132-140 in C
-        table = _native.host_build_table(np.ascontiguousarray(src, np.float32), q["cf1"], q["cf2"])
-        denorm = _native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
-        n = table.shape[0]
+        # keypoint table and de-normalisation written straight into ONE page-locked staging block: a single asynchronous copy.
+        # (A copy from pageable memory, however small, queues behind the 25 MB image copy in the runtime: measured 350 us of
+        # waiting, the solve starting when the upload had finished - tools/pipeline_order.py, profiles/r04_pipeline_overlap.txt.)
+        n = int(np.asarray(src).shape[0])
+        nt, nd = n * _native.TABLE_STRIDE, _native.DENORM_DOUBLES
+        stage = self._staging(nt + nd)
+        table = _native.host_build_table(np.ascontiguousarray(src, np.float32), q["cf1"], q["cf2"], out=stage[:nt].reshape(n, _native.TABLE_STRIDE))
+        _native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"], out=stage[nt:nt + nd])
         t1 = time.perf_counter()
         with torch.cuda.device(self.dev):
             stream = self._stream()
             main = torch.cuda.current_stream(self.dev)
-            d_table = self._up("table", table, torch.float64)
-            d_den = self._up("denorm", denorm, torch.float64)
+            mark("main: first enqueue")
+            d_stage = self._get("stage", (nt + nd,), torch.float64)
+            d_stage.copy_(self._stage_t[:nt + nd], non_blocking=True)
+            d_table, d_den = d_stage[:nt].view(n, _native.TABLE_STRIDE), d_stage[nt:]
             if vertices is None:
                 d_vert = plan.vertices
             else:
@@ -189,7 +227,9 @@ class Pipeline:
             if plan is not None:
                 # the solve that leaves every cell warp ready in the plan's workspace (apap_solve_warp_batch_device)
                 plan.status.zero_()
+                mark("small uploads done")
                 plan.solve(d_table, d_den, d_vert, float(gamma), float(sigma), out=d_H, work=d_work)
+                mark("solve done")
             else:
                 _native.check(lib.apap_solve_device(self._h, d_table.data_ptr(), n, d_vert.data_ptr(), cells, float(gamma), float(sigma),
                                                     d_den.data_ptr(), d_H.data_ptr(), d_work.data_ptr(), nb, stream))
@@ -207,6 +247,7 @@ class Pipeline:
                 if early is not None:
                     d_img, d_cen, ev = early
                     main.wait_event(ev)
+                    mark("image here")
                     cen = center_img
                 else:
                     d_img = self._up("img", img, torch.uint8)       # blocks the host while the GPU solves
@@ -217,6 +258,7 @@ class Pipeline:
                 d_out = self._get("canvas", (fh, fw, 3), torch.uint8)
                 if plan is not None:
                     plan.gather(d_img, out=d_out.view(1, fh, fw, 3), centers=d_cen)
+                    mark("warp done")
                 else:
                     d_mw = self._up("mesh_w", mesh[0], torch.float64)
                     d_mh = self._up("mesh_h", mesh[1], torch.float64)
@@ -228,22 +270,48 @@ class Pipeline:
                                                              d_H.data_ptr(), rows, cols, d_mw.data_ptr(), mesh.shape[1], d_mh.data_ptr(),
                                                              mesh.shape[1], fw, fh, ox, oy, 0, fh, d_out.data_ptr(), 0, None, 1,
                                                              _native.WARP_ALL, d_ww.data_ptr(), wb, d_status.data_ptr(), stream))
+            # the status word follows the last kernel into page-locked memory: read after the final synchronisation, no copy of its own
+            if getattr(self, "_status_host", None) is None:
+                self._status_host = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            self._status_host.copy_(d_status, non_blocking=True)
             t2 = time.perf_counter()
             # the .mat array comes down on the side stream beside the warp kernel, the canvas after it
+            flat = flat_done = None
             with torch.cuda.stream(self._side):
                 self._side.wait_event(flat_ready)
-                flat = self._down(d_flat)
+                if pinned_in:
+                    # page-locked staging, copied into the result while the canvas comes down.  NOT a copy into pageable memory:
+                    # one pageable copy on the side stream and, from the next pass on, the small uploads on the main stream wait
+                    # for the whole image upload on the side stream (tools/torch_copy_overlap.py: 476 instead of 55 us)
+                    if getattr(self, "_flat_host", None) is None or self._flat_host.numel() < cells * 9:
+                        self._flat_host = torch.empty(cells * 9, dtype=torch.float64, pin_memory=True)
+                    self._flat_host[:cells * 9].copy_(d_flat.view(-1), non_blocking=True)
+                    flat_done = torch.cuda.Event()
+                    flat_done.record(self._side)
+                else:
+                    flat = self._down(d_flat)
             if d_out is not None and canvas_out is not None:
                 if canvas_out.shape != (fh, fw, 3) or canvas_out.dtype != np.uint8 or not canvas_out.flags.c_contiguous:
                     raise ValueError(f"canvas_out must be a contiguous uint8 array of shape {(fh, fw, 3)}")
                 torch.from_numpy(canvas_out).copy_(d_out, non_blocking=True)
+                mark("canvas down")
+                if flat_done is not None:
+                    flat_done.synchronize()
+                    flat = self._flat_host[:cells * 9].numpy().reshape(cells, 9).copy()
                 main.synchronize()
                 canvas = canvas_out
             else:
+                if flat_done is not None:
+                    flat_done.synchronize()
+                    flat = self._flat_host[:cells * 9].numpy().reshape(cells, 9).copy()
                 canvas = self._down(d_out) if d_out is not None else None      # (synchronises the main stream)
-            status = int(d_status.cpu()[0])
+            main.synchronize()
+            status = int(self._status_host[0])
             grid = self._down(d_H).reshape(rows, cols, 3, 3) if want_grid else None
         t3 = time.perf_counter()
+        if marks:
+            torch.cuda.synchronize(self.dev)
+            self.device_marks = [(n, marks[0][1].elapsed_time(e) * 1e3) for n, e in marks]
         self.timeline = {"host_setup_ms": (t1 - t0) * 1e3, "upload_and_enqueue_ms": (t2 - t1) * 1e3,
                          "sync_and_download_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3}
         if status & 1:

@@ -1025,6 +1025,35 @@ def test_overlapped_host_warp_on_buffers_that_share_pages(native, golden):
         ovl.close()
 
 
+def test_overlapped_host_warp_on_buffers_the_caller_page_locked(native, golden):
+    """Image and canvas already page-locked by the caller (torch's pin_memory = hipHostMalloc): the banded path must take them
+    as they are - hipHostRegister on such memory fails, which used to send the call down the sequential path - neither
+    register nor unregister them (they stay page-locked afterwards), and write the sequential call's canvas; `out=` of the
+    binding hands the caller's canvas through."""
+    import torch
+    g = golden("c2_ref")
+    p = config_pair("C2")
+    H = np.ascontiguousarray(g["H_ref"], dtype=np.float32)
+    ref, hinv_ref = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    pin_img = torch.empty(p.img.shape, dtype=torch.uint8, pin_memory=True)
+    pin_img.numpy()[...] = p.img
+    pin_out = torch.zeros(ref.shape, dtype=torch.uint8, pin_memory=True)
+    ovl = native.Context(overlap_pcie=1)
+    try:
+        for _ in range(2):
+            pin_out.zero_()
+            out, hinv = native.local_warp(pin_img.numpy(), H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, ctx=ovl,
+                                          out=pin_out.numpy())
+            assert out is not None and out.ctypes.data == pin_out.data_ptr()
+            assert np.array_equal(pin_out.numpy(), ref) and np.array_equal(hinv, hinv_ref)
+            assert pin_img.is_pinned() and pin_out.is_pinned()
+            assert np.array_equal(pin_img.numpy(), p.img)
+    finally:
+        ovl.close()
+    with pytest.raises(ValueError):
+        native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y, out=np.empty((3, 3, 3), np.uint8))
+
+
 def test_source_with_a_side_of_2_to_the_24_takes_the_flat_order_kernel(native):
     """The strip kernel forms source offsets with 24-bit multiplies; a source with a side of 2^24
     pixels must be dispatched to the flat-order kernel (apap_kernels.hip warp_impl) - and still give

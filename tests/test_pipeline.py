@@ -74,3 +74,35 @@ def test_page_locked_buffers_give_the_same_bytes(native, golden):
             assert hashlib.sha256(canvas_b.tobytes()).digest() == golden("c2_ref")["warped_sha256"].tobytes()
     with pytest.raises(ValueError):
         pipe.run_pair(*args, other_img=img_pin, canvas_out=np.zeros((3, 3, 3), np.uint8))
+
+
+def test_page_locked_passes_in_a_row_do_not_share_results(native):
+    """The page-locked pass builds its keypoint table in a staging block and takes the ``.mat`` array and the status word
+    through staging: consecutive passes on DIFFERENT pairs must each give their own result (an earlier pass's array is the
+    caller's, not a view of the staging), with and without ``canvas_out``, and the status of a singular grid still raises."""
+    from cvx_proj_amd.pipeline import Pipeline
+    from cvx_proj_amd.synth import synth_pair
+    pipe, plain = Pipeline(), Pipeline()
+    pairs = [synth_pair(640, 360, 300, 20, seed) for seed in (5, 6, 7)]
+    img_pin = pipe.pinned_array(pairs[0].img.shape)
+    kept = []
+    for k, p in enumerate(pairs):
+        m = p.vertices.shape[0]
+        args = (p.src, p.dst, p.Hg, p.shape, p.shape, m, p.gamma, p.sigma)
+        np.copyto(img_pin, p.img)
+        out_pin = pipe.pinned_array((p.final_h, p.final_w, 3)) if k != 1 else None
+        flat, canvas = pipe.run_pair(*args, other_img=img_pin, canvas_out=out_pin)
+        flat_ref, canvas_ref = plain.run_pair(*args, other_img=p.img)
+        assert np.array_equal(flat, flat_ref) and np.array_equal(canvas, canvas_ref)
+        lo = pipe._flat_host.data_ptr()
+        assert not lo <= flat.ctypes.data < lo + pipe._flat_host.numel() * 8          # the caller's own memory, not the staging
+        kept.append((flat, flat_ref.copy()))
+    for flat, ref in kept:          # later passes did not write into earlier results
+        assert np.array_equal(flat, ref)
+    p = pairs[0]
+    np.copyto(img_pin, p.img)
+    with pytest.raises(np.linalg.LinAlgError):
+        # every keypoint the same point: a singular system in every cell (the reference: LinAlgError from np.linalg.inv)
+        pipe.run_pair(np.zeros_like(p.src), np.zeros_like(p.dst), p.Hg, p.shape, p.shape, 20, p.gamma, p.sigma, other_img=img_pin)
+    flat, canvas = pipe.run_pair(p.src, p.dst, p.Hg, p.shape, p.shape, 20, p.gamma, p.sigma, other_img=img_pin)
+    assert np.array_equal(flat, kept[0][1])     # and the pipeline works on afterwards
