@@ -269,7 +269,11 @@ int pipe_prepare(apap_ctx *pool, int dev, size_t n_events, size_t pinned_bytes) 
         }
     while (pool->events.size() < n_events) {
         hipEvent_t e;
+#ifdef APAP_TRACE_PIPE
+        APAP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDefault));       // the diagnostic build prints the device's own timeline
+#else
         APAP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+#endif
         pool->events.push_back(e);
     }
     if (pool->pinned_cap < pinned_bytes) {
@@ -312,10 +316,16 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     const size_t cbytes = center ? (size_t)center_h * center_w * 3 : 0;
     if (img_bytes + out_bytes < (8u << 20)) return APAP_OK;      // small pairs: one copy each way is as good
     const int cells = mesh_rows * mesh_cols;
-    const int chunks = (int)std::min<size_t>(16, std::max<size_t>(2, img_bytes / (3u << 20)));
-    const int bands = (int)std::min<size_t>(16, std::max<size_t>(2, out_bytes / (3u << 20)));
+    int chunks = (int)std::min<size_t>(16, std::max<size_t>(2, img_bytes / (3u << 20)));
+    int bands = (int)std::min<size_t>(16, std::max<size_t>(2, out_bytes / (3u << 20)));
+    bool small_first = false;
+#ifdef APAP_TRACE_PIPE      // experiments of the diagnostic build only
+    if (const char *e = getenv("APAP_PIPE_CHUNKS")) chunks = std::min(std::max(atoi(e), 1), 16);
+    if (const char *e = getenv("APAP_PIPE_BANDS")) bands = std::min(std::max(atoi(e), 1), 16);
+    if (const char *e = getenv("APAP_PIPE_SMALL_FIRST")) small_first = atoi(e) != 0;
+#endif
     const size_t range_ints = (size_t)mesh_rows * 2 + 2;
-    int rc = pipe_prepare(pool, dev, (size_t)2 * chunks + bands + 2, range_ints * sizeof(int) + 64);
+    int rc = pipe_prepare(pool, dev, (size_t)2 * chunks + 2 * bands + 4, range_ints * sizeof(int) + 64);
     if (rc) return rc;
     // Only the three big buffers are pinned, and only when no two of them share a page.  History: with the grid and its
     // inverse pinned as well (numpy's `H.copy()` followed by `np.empty_like(H)`: back to back) one run of round 3 ended in a
@@ -354,21 +364,29 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     hipStream_t s_up = (hipStream_t)pool->streams[0], s_k = (hipStream_t)pool->streams[1], s_dn = (hipStream_t)pool->streams[2];
     hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(pool->events.data());
     hipEvent_t *e_img = ev, *e_cen = ev + chunks, *e_band = ev + 2 * chunks, e_setup = ev[2 * chunks + bands];
+#ifdef APAP_TRACE_PIPE
+    hipEvent_t *e_down = ev + 2 * chunks + bands + 2, e_start = ev[2 * chunks + bands + 1];
+    APAP_HIP_TRY(hipEventRecord(e_start, s_up));
+#endif
     int *h_rng = (int *)pool->pinned;
     int status = 0;
     const DrainStreams drain{pool};     // declared after everything the streams read or write
 
     // upload stream: source rows (and the centre image's) in chunks, an event after each
-    for (int c = 0; c < chunks; ++c) {
-        const size_t a = (size_t)cut(img_h, chunks, c) * img_w * 3, b = (size_t)cut(img_h, chunks, c + 1) * img_w * 3;
-        if (b > a) APAP_HIP_TRY(hipMemcpyAsync((char *)d_img + a, img + a, b - a, hipMemcpyHostToDevice, s_up));
-        APAP_HIP_TRY(hipEventRecord(e_img[c], s_up));
-        if (center) {
-            const size_t ca = (size_t)cut(center_h, chunks, c) * center_w * 3, cb = (size_t)cut(center_h, chunks, c + 1) * center_w * 3;
-            if (cb > ca) APAP_HIP_TRY(hipMemcpyAsync((char *)d_center + ca, center + ca, cb - ca, hipMemcpyHostToDevice, s_up));
-            APAP_HIP_TRY(hipEventRecord(e_cen[c], s_up));
+    auto enqueue_uploads = [&]() -> int {
+        for (int c = 0; c < chunks; ++c) {
+            const size_t a = (size_t)cut(img_h, chunks, c) * img_w * 3, b = (size_t)cut(img_h, chunks, c + 1) * img_w * 3;
+            if (b > a) APAP_HIP_TRY(hipMemcpyAsync((char *)d_img + a, img + a, b - a, hipMemcpyHostToDevice, s_up));
+            APAP_HIP_TRY(hipEventRecord(e_img[c], s_up));
+            if (center) {
+                const size_t ca = (size_t)cut(center_h, chunks, c) * center_w * 3, cb = (size_t)cut(center_h, chunks, c + 1) * center_w * 3;
+                if (cb > ca) APAP_HIP_TRY(hipMemcpyAsync((char *)d_center + ca, center + ca, cb - ca, hipMemcpyHostToDevice, s_up));
+                APAP_HIP_TRY(hipEventRecord(e_cen[c], s_up));
+            }
         }
-    }
+        return APAP_OK;
+    };
+    if (!small_first && (rc = enqueue_uploads())) return rc;
 
     stamp("uploads enqueued");
     // kernels stream: grid and edges up, set-up kernel, its source-row intervals back
@@ -404,6 +422,7 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     if (rc) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(h_rng, d_src_rows, range_ints * sizeof(int), hipMemcpyDeviceToHost, s_k));
     APAP_HIP_TRY(hipEventRecord(e_setup, s_k));
+    if (small_first && (rc = enqueue_uploads())) return rc;
     if (Hinv_out)
         APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, s_k));
 
@@ -452,6 +471,9 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
         APAP_HIP_TRY(hipEventRecord(e_band[b], s_k));
         APAP_HIP_TRY(hipStreamWaitEvent(s_dn, e_band[b], 0));
         APAP_HIP_TRY(hipMemcpyAsync(out + (size_t)y0 * final_w * 3, d_band, (size_t)(y1 - y0) * final_w * 3, hipMemcpyDeviceToHost, s_dn));
+#ifdef APAP_TRACE_PIPE
+        APAP_HIP_TRY(hipEventRecord(e_down[b], s_dn));
+#endif
     }
     stamp("bands enqueued");
     APAP_HIP_TRY(hipMemcpyAsync(h_rng, d_status, sizeof(int), hipMemcpyDeviceToHost, s_k));
@@ -461,6 +483,22 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     APAP_HIP_TRY(hipStreamSynchronize(s_dn));
     stamp("downloads done");
     APAP_HIP_TRY(hipStreamSynchronize(s_up));
+#ifdef APAP_TRACE_PIPE
+    {
+        auto at = [&](hipEvent_t e) {
+            float ms = -1.f;
+            if (hipEventElapsedTime(&ms, e_start, e) != hipSuccess) (void)hipGetLastError();
+            return ms * 1e3f;
+        };
+        fprintf(stderr, "[pipe] device: set-up done %.0f | chunk landed", at(e_setup));
+        for (int c = 0; c < chunks; ++c) fprintf(stderr, " %.0f", at(e_img[c]));
+        fprintf(stderr, " | band warped");
+        for (int b = 0; b < bands; ++b) fprintf(stderr, " %.0f", at(e_band[b]));
+        fprintf(stderr, " | band down");
+        for (int b = 0; b < bands; ++b) fprintf(stderr, " %.0f", at(e_down[b]));
+        fprintf(stderr, " us\n");
+    }
+#endif
     *done = true;
     return status_to_code(status, who);
 }
