@@ -316,14 +316,10 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     const size_t cbytes = center ? (size_t)center_h * center_w * 3 : 0;
     if (img_bytes + out_bytes < (8u << 20)) return APAP_OK;      // small pairs: one copy each way is as good
     const int cells = mesh_rows * mesh_cols;
-    int chunks = (int)std::min<size_t>(16, std::max<size_t>(2, img_bytes / (3u << 20)));
-    int bands = (int)std::min<size_t>(16, std::max<size_t>(2, out_bytes / (3u << 20)));
-    bool small_first = false;
-#ifdef APAP_TRACE_PIPE      // experiments of the diagnostic build only
-    if (const char *e = getenv("APAP_PIPE_CHUNKS")) chunks = std::min(std::max(atoi(e), 1), 16);
-    if (const char *e = getenv("APAP_PIPE_BANDS")) bands = std::min(std::max(atoi(e), 1), 16);
-    if (const char *e = getenv("APAP_PIPE_SMALL_FIRST")) small_first = atoi(e) != 0;
-#endif
+    // (chunks x bands x order were swept in round 4 - profiles/r04_pcie_duplex.txt: a plateau at 0.89-0.93 ms for 4-8 chunks and 4-8
+    // bands; grid upload + set-up before the image chunks is worse whenever the inverses come back)
+    const int chunks = (int)std::min<size_t>(16, std::max<size_t>(2, img_bytes / (3u << 20)));
+    const int bands = (int)std::min<size_t>(16, std::max<size_t>(2, out_bytes / (3u << 20)));
     const size_t range_ints = (size_t)mesh_rows * 2 + 2;
     int rc = pipe_prepare(pool, dev, (size_t)2 * chunks + 2 * bands + 4, range_ints * sizeof(int) + 64);
     if (rc) return rc;
@@ -386,7 +382,7 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
         }
         return APAP_OK;
     };
-    if (!small_first && (rc = enqueue_uploads())) return rc;
+    if ((rc = enqueue_uploads())) return rc;
 
     stamp("uploads enqueued");
     // kernels stream: grid and edges up, set-up kernel, its source-row intervals back
@@ -422,7 +418,6 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     if (rc) return rc;
     APAP_HIP_TRY(hipMemcpyAsync(h_rng, d_src_rows, range_ints * sizeof(int), hipMemcpyDeviceToHost, s_k));
     APAP_HIP_TRY(hipEventRecord(e_setup, s_k));
-    if (small_first && (rc = enqueue_uploads())) return rc;
     if (Hinv_out)
         APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, s_k));
 

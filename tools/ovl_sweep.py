@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """apap_local_warp with APAP_OPT_OVERLAP_PCIE = 1 on C3: upload chunks x download bands x order (small uploads + set-up before or after the image
-chunks are enqueued), median host clock of 15 calls on reused buffers.  Needs the -DAPAP_TRACE_PIPE build (it reads the three environment
-variables; its stderr timeline is discarded here):  APAP_HIP_LIB=$PWD/tools/variants/lib_trace_pipe.so python tools/ovl_sweep.py 2>/dev/null"""
+chunks are enqueued), median host clock of 15 calls on reused buffers.  Ran against a diagnostic build of round 4 that read the three environment variables
+(removed again: the library reads no environment; profiles/r04_pcie_duplex.txt has the table) - kept as the record of the method:  APAP_HIP_LIB=$PWD/tools/variants/lib_trace_pipe.so python tools/ovl_sweep.py 2>/dev/null"""
 import os
 import sys
 import time
