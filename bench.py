@@ -633,8 +633,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend = None
-    if world > 1:
+    # APAP_BENCH_FORCE_GROUP=1: a process group (and every collective of the multi-rank code paths) also with ONE rank - first contact
+    # with RCCL's initialisation and collectives on a one-GPU box (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment)
+    if world > 1 or os.environ.get("APAP_BENCH_FORCE_GROUP") == "1":
         import torch.distributed as dist
+        if world == 1:
+            import cvx_proj_amd.dist as _D
+            _D.REHEARSE_ONE_RANK = True     # the one rank runs the broadcasts and all-gathers of `cells` instead of the single-process shortcuts
         backend = os.environ.get("APAP_BENCH_BACKEND", "nccl")      # nccl = RCCL on ROCm
         # first contact with RCCL must not hang silently: a short collective timeout (the default is 10 minutes, the
         # driver's limit for the whole run is not much more) and a phase marker on stderr before every phase that

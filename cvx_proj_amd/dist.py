@@ -210,6 +210,17 @@ class WarpPlan:
         return out
 
 
+# Rehearsals only (tests/_dist_gpu_ranks.py, tests/test_dist_gloo.py): True = a process group of ONE rank does not take the
+# single-process shortcuts - every broadcast / all-gather of the multi-rank path runs, through the group's backend, with the real
+# tensors.  This is how RCCL sees these collectives on a one-GPU box (it refuses two ranks on one device).
+REHEARSE_ONE_RANK = False
+
+
+def _collective(dist, world):
+    """Does the multi-rank path (with its collectives) apply?"""
+    return dist is not None and (world > 1 or REHEARSE_ONE_RANK)
+
+
 class ShardedSolver:
     """Mesh rows of ONE pair sharded over the ranks of ``dist`` (None = single process).
 
@@ -256,7 +267,7 @@ class ShardedSolver:
         # a _native.Context (options, profiling) handed to the default HIP compute functions
         self._ctx = ctx
         self._kw = {"ctx": ctx} if ctx is not None else {}
-        self.overlap = (2 <= self.world <= 4) if overlap == "auto" else (bool(overlap) and self.world > 1)
+        self.overlap = (2 <= self.world <= 4) if overlap == "auto" else (bool(overlap) and _collective(dist, self.world))
         self.n = len(pair.src)
         self.parts = row_partition(self.rows, self.world)
         self.max_rows = max(b - a for a, b in self.parts)
@@ -302,7 +313,7 @@ class ShardedSolver:
         """Keypoint table (n x 256 B) and de-normalisation block from rank 0 to every rank:
         once per pair, not once per solve."""
         d = self.dist
-        if d is not None and self.world > 1:
+        if _collective(d, self.world):
             d.broadcast(self.table, src=0)
             d.broadcast(self.denorm, src=0)
         self._inputs_sent = True
@@ -326,7 +337,7 @@ class ShardedSolver:
         if not self._inputs_sent:
             self.broadcast_inputs()
         self.finish()
-        if d is None or self.world == 1:
+        if not _collective(d, self.world):
             mine = self._solve_piece(0)
             self.H.copy_(mine[:self.cells_total])
             return self.H
@@ -372,7 +383,7 @@ class ShardedSolver:
         edges = np.asarray(p.mesh[1], dtype=np.float64)
         # (edges that stop short of the canvas keep the unaligned bands: there the single-GPU path and the reference report an
         # index error for the uncovered rows, apap.py:207 - opening the last edge to +inf would silently warp them)
-        self._aligned = (self.world > 1 and len(edges) == self.rows + 1 and bool(np.all(np.diff(edges) > 0)) and edges[0] <= 0.0
+        self._aligned = (_collective(d, self.world) and len(edges) == self.rows + 1 and bool(np.all(np.diff(edges) > 0)) and edges[0] <= 0.0
                          and bool(np.isfinite(edges).all()) and edges[-1] >= p.final_h)
         if self._aligned:
             first = lambda k: int(min(max(np.ceil(edges[k]), 0.0), p.final_h)) if k < self.rows else p.final_h   # noqa: E731
@@ -385,7 +396,7 @@ class ShardedSolver:
             self.img = torch.from_numpy(np.ascontiguousarray(p.img)).to(self.dev)
         else:
             self.img = torch.zeros(p.shape, dtype=torch.uint8, device=self.dev)
-        if d is not None and self.world > 1:
+        if _collective(d, self.world):
             d.broadcast(self.img, src=0)
         self.mesh_w = torch.from_numpy(np.ascontiguousarray(p.mesh[0])).to(self.dev)
         ra, rb = self.my_rows
@@ -422,7 +433,7 @@ class ShardedSolver:
             self._warp_setup()
         p, d = self.pair, self.dist
         a, b = self.bands[self.rank]
-        single = d is None or self.world == 1
+        single = not _collective(d, self.world)
         if self._aligned:
             ra, rb = self.my_rows
             H = self.H[ra * self.cols:rb * self.cols]           # this rank's own rows: valid before the gather ends
@@ -469,7 +480,7 @@ def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
         for p, table, den in zip(my_pairs, tables, dens):
             vert = torch.from_numpy(np.ascontiguousarray(p.vertices.reshape(-1, 2))).to(dev)
             mine.append(solve_fn(table.to(dev), den.to(dev), vert, p.gamma, p.sigma))
-    if dist is None or world == 1:
+    if not _collective(dist, world):
         return [h.cpu().numpy().reshape(p.vertices.shape[0], p.vertices.shape[1], 3, 3) for h, p in zip(mine, pairs)]
     per_rank = (len(pairs) + world - 1) // world
     cells = pairs[0].vertices.shape[0] * pairs[0].vertices.shape[1]
@@ -524,7 +535,7 @@ def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=Fals
     buf = torch.zeros((per_rank, p0.final_h, p0.final_w, 3), dtype=torch.uint8, device=dev)
     for i, k in enumerate(mine):
         buf[i].copy_(canv[k])
-    if dist is None or world == 1:
+    if not _collective(dist, world):
         return [buf[k].cpu().numpy() for k in range(len(pairs))]
     if dist.get_backend() == "nccl":
         allbuf = torch.zeros((world,) + tuple(buf.shape), dtype=buf.dtype, device=dev)

@@ -22,10 +22,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     else:
         dist.init_process_group("gloo")
+    from cvx_proj_amd import dist as D
     from cvx_proj_amd.dist import ShardedSolver, solve_pairs
     from cvx_proj_amd.synth import config_pair
+    if world == 1:
+        # one rank on its own device = the nccl backend: do not take the single-process shortcuts, so that RCCL runs every
+        # broadcast and all-gather of the multi-rank path once with the real tensors
+        D.REHEARSE_ONE_RANK = True
     p = config_pair(cfg, with_image=(rank == 0))
-    s = ShardedSolver(p, dev, dist)
+    s = ShardedSolver(p, dev, dist, overlap=True if world == 1 else "auto")
     if rank != 0:
         assert float(s.table.abs().sum()) == 0.0          # the table lives on rank 0 until the broadcast
     H = s.solve().cpu().numpy().copy()

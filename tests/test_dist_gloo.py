@@ -295,3 +295,49 @@ def test_same_bits_leaves_the_caller_s_context_alone_and_short_meshes_keep_unali
         s._warp_setup()
         assert s._aligned == (not short)
         assert s.bands[0][0] == 0 and s.bands[-1][1] == q.final_h
+
+
+def test_one_rank_rehearsal_runs_every_collective():
+    """dist.REHEARSE_ONE_RANK: a group of ONE rank that does not take the single-process shortcuts - table broadcast, split H
+    all-gather (both forms), image broadcast, aligned band + canvas all-gather, the pairs' gathers all run through the backend
+    (here gloo; tests/test_gpu_dist.py runs the same switch over nccl = RCCL on the one-GPU box) - and gives the
+    single-process results."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from cvx_proj_amd import dist as D
+    from cvx_proj_amd.synth import synth_pair
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    calls = []
+    real = {name: getattr(dist, name) for name in ("broadcast", "all_gather_into_tensor", "gather")}
+    try:
+        for name, fn in real.items():
+            setattr(dist, name, (lambda fn, name: lambda *a, **k: (calls.append(name), fn(*a, **k))[1])(fn, name))
+        p = synth_pair(320, 240, 80, 6, seed=9)
+        cpu = torch.device("cpu")
+        plain = D.ShardedSolver(p, cpu, None, solve_fn=oracle_solve, warp_fn=oracle_warp_rows)
+        H0, canvas0 = plain.solve().numpy().copy(), plain.warp().numpy().copy()
+        assert calls == []
+        D.REHEARSE_ONE_RANK = True
+        for overlap in (True, False):
+            calls.clear()
+            s = D.ShardedSolver(p, cpu, dist, solve_fn=oracle_solve, warp_fn=oracle_warp_rows, overlap=overlap)
+            assert s.overlap == overlap
+            assert np.array_equal(s.solve().numpy(), H0)
+            assert np.array_equal(s.warp().numpy(), canvas0) and s._aligned
+            H_step, band = s.step()
+            assert np.array_equal(H_step.numpy(), H0) and np.array_equal(band.numpy(), canvas0)
+            assert calls.count("broadcast") == 3 and calls.count("all_gather_into_tensor") >= (2 if overlap else 1) + 1, calls
+        pairs = [synth_pair(160, 120, 40, 3, seed=50 + k) for k in range(3)]
+        calls.clear()
+        grids = D.solve_pairs(pairs, cpu, dist, solve_fn=oracle_solve)
+        canv = D.warp_pairs(pairs, grids, cpu, dist, warp_fn=oracle_warp_batch, gather=True)
+        assert "gather" in calls
+        D.REHEARSE_ONE_RANK = False
+        grids0 = D.solve_pairs(pairs, cpu, None, solve_fn=oracle_solve)
+        canv0 = D.warp_pairs(pairs, grids0, cpu, None, warp_fn=oracle_warp_batch, gather=True)
+        assert all(np.array_equal(a, b) for a, b in zip(grids, grids0)) and all(np.array_equal(a, b) for a, b in zip(canv, canv0))
+    finally:
+        D.REHEARSE_ONE_RANK = False
+        for name, fn in real.items():
+            setattr(dist, name, fn)
+        dist.destroy_process_group()

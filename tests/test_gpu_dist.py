@@ -31,8 +31,10 @@ def clean_env(**extra):
     return env
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3])
 def test_sharded_solver_ranks_equal_single_gpu(native, tmp_path, world):
+    """world = 1 runs over nccl = RCCL (one rank per device: every collective of ShardedSolver, step()'s asynchronous gather and
+    solve_pairs' gather go through RCCL once); 2 and 3 ranks share the one GPU of the box and talk over gloo."""
     out = str(tmp_path / "ranks.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_dist_gpu_ranks.py"), out, "C2"]
@@ -86,3 +88,23 @@ def test_bench_self_launch_reports_pairs_and_cells(native):
     assert c["collectives_overlapped"] is True and c["solve_other_form_ms_per_step"] > 0 and c["pipelined_step"]["ms_per_step"] > 0
     one = d["roofline"]["frac"]
     assert c["roofline"]["frac"] < 2.5 * one                          # not inflated by the world size
+
+
+def test_bench_with_a_one_rank_rccl_group():
+    """First contact with RCCL on a one-GPU box: bench.py with APAP_BENCH_FORCE_GROUP=1 builds an `nccl` process group of ONE rank and
+    walks every multi-rank code path through it - the first all-reduce, the barriers, the table broadcast, the H all-gather and the
+    canvas all-gather of `cells`, the max-over-ranks of the timings - with the real tensors (dtypes, contiguity, device).  One JSON
+    line, the phase markers on stderr, the same canvases (bench.py asserts them)."""
+    env = clean_env(APAP_BENCH_FORCE_GROUP="1")
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.pop("APAP_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--condition-ms", "0", "--no-cpu-baseline",
+                        "--no-call-level", "--cells-config", "C2", "--c5-pairs", "4"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["cells"]["value"] > 0 and d["pairs"]["warp"]["value"] > 0
+    phases = [json.loads(ln)["bench_phase"] for ln in r.stderr.splitlines() if ln.startswith('{"bench_phase"')]
+    assert phases[:2] == ["process group up", "first collective done"] and any(p.startswith("cells") for p in phases)
+    assert all(json.loads(ln)["backend"] == "nccl" for ln in r.stderr.splitlines() if ln.startswith('{"bench_phase"'))
