@@ -134,3 +134,41 @@ passes2("+ page-locked 2.9 MB download on side, no wait", True, False, False)
 passes2("+ page-locked 2.9 MB download on side after side.wait_event(main's event)", True, False, True)
 passes2("+ pageable 2.9 MB download on side, no wait", True, True, False)
 passes2("+ pageable 2.9 MB download on side after side.wait_event(main's event)", True, True, True)
+
+# ---- what could a banded canvas download buy the page-locked pipeline pass?  upload in `chunks` pieces on side; from `start_us` on (the solve
+#      is done, the row ranges are known) download in `bands` pieces on a third stream, each after "its" chunk; no kernels in between ----
+def banded(chunks, bands, start_us, n=6):
+    side, down = s1, s3
+    res = []
+    cb, db = big_h.numel() // chunks, down_h.numel() // bands
+    for i in range(n):
+        torch.cuda.synchronize()
+        e0, e_up, e_dn = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        landed = []
+        t0 = time.perf_counter()
+        e0.record(side)
+        with torch.cuda.stream(side):
+            for c in range(chunks):
+                big_d[c * cb:(c + 1) * cb].copy_(big_h[c * cb:(c + 1) * cb], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                landed.append(ev)
+            e_up.record(side)
+        while (time.perf_counter() - t0) * 1e6 < start_us:
+            pass
+        with torch.cuda.stream(down):
+            for b in range(bands):
+                down.wait_event(landed[min(chunks - 1, (b + 1) * chunks // bands)])      # band b reads up to the chunk below it
+                down_h[b * db:(b + 1) * db].copy_(down_d[b * db:(b + 1) * db], non_blocking=True)
+            e_dn.record(down)
+        torch.cuda.synchronize()
+        res.append((e0.elapsed_time(e_up) * 1e3, e0.elapsed_time(e_dn) * 1e3, (time.perf_counter() - t0) * 1e6))
+    res.sort(key=lambda r: r[2])
+    u, d, w = res[len(res) // 2]
+    print(f"chunks {chunks:2d} bands {bands:2d} downloads from {start_us:4d} us: upload done {u:5.0f}  download done {d:5.0f}  wall {w:5.0f} us")
+
+
+print("banded download against the upload's tail (page-locked, no kernels):")
+banded(1, 1, 0)
+for ch, bd in ((4, 4), (4, 8), (8, 8), (2, 4)):
+    banded(ch, bd, 370)
