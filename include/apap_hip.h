@@ -116,7 +116,8 @@ typedef struct apap_ctx apap_ctx;
                                       and takes the exact float64 sequence only where the estimate is within its error
                                       bound of an integer (same canvas, byte for byte); 0: float64 for every pixel    */
 #define APAP_OPT_OVERLAP_PCIE 9    /* 0 (default): apap_local_warp / apap_local_stitch make one copy up, one kernel, one copy
-                                      down.  1: they pin the caller's buffers for the call (hipHostRegister) and overlap the
+                                      down.  1: they pin the caller's buffers for the call (hipHostRegister; buffers the caller already page-locked -
+                                      hipHostMalloc, its own registration - are taken as they are) and overlap the
                                       image upload, the warp (in row bands) and the canvas download on three streams.  For
                                       callers that REUSE their image / canvas buffers: the first uses of a buffer pay 8-26 ms of
                                       pinning and mapping (4K pair), every later call saves ~15 %                              */
