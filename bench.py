@@ -975,6 +975,26 @@ def main():
         torch.cuda.synchronize()
         ckern = read_kernel_ms(ctx)
         ctx.set("profile", 0)
+        # K3 alone on this configuration's whole canvas (one rank): the gather kernel on a kept workspace, launches back to back
+        c_k3 = None
+        if world == 1 and cp.img is not None:
+            from cvx_proj_amd.dist import WarpPlan
+            wp = WarpPlan(cp.mesh, (cs.rows, cs.cols), cp.final_w, cp.final_h, cp.off_x, cp.off_y, dev, ctx=ctx)
+            wp.cells(cs.H)
+            c_img = torch.from_numpy(np.ascontiguousarray(cp.img)).to(dev)
+            c_out = torch.empty((1, cp.final_h, cp.final_w, 3), dtype=torch.uint8, device=dev)
+            for _ in range(5):
+                wp.gather(c_img, out=c_out)
+            c_ms = back_to_back(lambda: wp.gather(c_img, out=c_out), max(a.steps, 20))
+            assert torch.equal(c_out[0], cs.warp()) and int(wp.status.cpu()[0]) == 0
+            c_nz = int((c_out[0].amax(dim=2) > 0).sum().cpu())
+            c_bytes = 6 * c_nz + 3 * (cp.final_w * cp.final_h - c_nz)
+            c_k3 = {"kernel": "k_warp_fast, whole canvas of this configuration, warm, launches back to back", "bound": "hbm",
+                    "kernel_ms": c_ms, "algorithmic_bytes": c_bytes, "achieved": c_bytes / (c_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": c_bytes / (c_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "note": "the same kernel as roofline_warp on a 4 x larger canvas: its time is ~4.5 us per launch + bytes at a "
+                            "marginal rate (profiles/r04_k3_experiments.txt), so the fraction grows with the canvas"}
+            del wp, c_img, c_out
         c_flops = K1_FLOPS_PER_CELL_POINT * cs.n * cs.my_cells       # THIS rank's cells: what its K1 launch worked on
         c_ach = c_flops / (ckern["assemble"] * 1e-3) / 1e12 if ckern.get("assemble") else None
         cells_obj = {
@@ -1008,6 +1028,7 @@ def main():
             "roofline": None if c_ach is None else {
                 "kernel": "k_assemble (rank 0's shard)", "bound": "mfma", "achieved": c_ach, "peak": PEAK_FP64_TFLOPS,
                 "unit": "TFLOP/s", "frac": c_ach / PEAK_FP64_TFLOPS},
+            "roofline_warp": c_k3,
         }
         del cs
 
