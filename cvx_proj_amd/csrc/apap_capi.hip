@@ -87,6 +87,8 @@ int status_to_code(int status, const char *who) {
     if (status & apap::kStatusSingular) return apap::fail(APAP_ERR_SINGULAR, "%s: Singular matrix", who);
     if (status & apap::kStatusIndex)
         return apap::fail(APAP_ERR_INDEX, "%s: index 0 is out of bounds for axis 0 with size 0 (mesh edges do not cover the canvas)", who);
+    if (status & apap::kStatusUnprepared)
+        return apap::fail(APAP_ERR_INVALID_ARG, "%s: the warp workspace holds no lookup tables for this mesh / canvas (APAP_WARP_GEOMETRY)", who);
     return APAP_OK;
 }
 

@@ -96,5 +96,6 @@ int warp_phase(apap_ctx *ctx, const uint8_t *d_img, int img_h, int img_w, const 
 constexpr int kMoments = 30;       // distinct sums of A^T W^2 A
 constexpr int kStatusSingular = 1; // bit 0 of the device status word
 constexpr int kStatusIndex = 2;    // bit 1
+constexpr int kStatusUnprepared = 4;   // bit 2: a gather on a workspace whose lookup tables were not built for this mesh / canvas
 
 }  // namespace apap

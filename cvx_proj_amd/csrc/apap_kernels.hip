@@ -1595,11 +1595,31 @@ __global__ __launch_bounds__(256) void k_invert_cells(const T *__restrict__ H, i
 // canvas row -> cell row and canvas column -> cell column:
 // "first k with i < edges[k]" minus one (apap.py:207,209-210), -1 wrapping to the last
 // cell like a Python index.  No monotonicity is assumed, hence the linear scan.
+// The lookup tables of a warp workspace (lut, fcol, frow) hold CELL INDICES: a gather that ran on a workspace whose tables were
+// never built - or were built for another mesh / canvas size - would index the per-cell tables with garbage.  The word behind
+// the lut carries a stamp of the sizes the tables were built for; every gather kernel compares it (one scalar load, issued with
+// its first table loads) before it uses a table VALUE as an index, and leaves with bit 2 of the status word otherwise.
+__host__ __device__ __forceinline__ int warp_stamp(int mesh_rows, int mesh_cols, int final_w, int final_h) {
+    return (int)(((unsigned)mesh_rows * 0x9E3779B1u) ^ ((unsigned)mesh_cols * 0x85EBCA77u) ^ ((unsigned)final_w * 0xC2B2AE3Du) ^
+                 ((unsigned)final_h * 0x27D4EB2Fu)) | 1;
+}
+// the same in 16 bits, never 0: carried by every row entry of the fast tables (frow[i].x = cell row | stamp16 << 16), so that
+// the strip kernel learns it from a load it makes anyway
+__host__ __device__ __forceinline__ unsigned warp_stamp16(int mesh_rows, int mesh_cols, int final_w, int final_h) {
+    return (((unsigned)warp_stamp(mesh_rows, mesh_cols, final_w, final_h) >> 12) & 0xffffu) | 1u;
+}
+__device__ __forceinline__ bool warp_tables_ready(int have, int mesh_rows, int mesh_cols, int final_w, int final_h, int *status) {
+    if (__builtin_expect(have == warp_stamp(mesh_rows, mesh_cols, final_w, final_h), 1)) return true;
+    if ((threadIdx.x & 63) == 0) atomicOr(status, apap::kStatusUnprepared);
+    return false;
+}
+
 __global__ __launch_bounds__(256) void k_cell_lut(const double *__restrict__ mesh_w, int n_w,
                                                   const double *__restrict__ mesh_h, int n_h,
                                                   int mesh_rows, int mesh_cols, int final_w,
                                                   int final_h, int *__restrict__ lut, int *status) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) lut[final_w + final_h] = warp_stamp(mesh_rows, mesh_cols, final_w, final_h);
     if (t >= final_h + final_w) return;
     const bool is_row = t < final_h;
     const int idx = is_row ? t : t - final_h;
@@ -1739,14 +1759,14 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
 
 // Workspace of the warp (every part rounded up to 256 bytes): first what depends on the mesh edges, the canvas and
 // the offsets only and is SHARED by all pairs of a batch,
-//   lut [final_h + final_w] i32 | fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
+//   lut [final_h + final_w] i32 + 1 stamp word | fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
 // then, per pair of the batch, what depends on that pair's H grid,
 //   hinv_pad [cells][10] f64 | frec [(rows + 1)(cols + 1)][3] float4 | fexact [(rows + 1)(cols + 1)][3] float4
 // fexact (column-walk kernel): the cell's stored float32 inverse as it is - 9 floats, then 1.0f when they ARE the inverse the
 // exact path must use (a float32 grid's ordinary cell), 0 otherwise (a float64 grid, the extra row / column) - so that a
 // pixel in doubt is settled from registers instead of through a dependent load of hinv_pad.
 // frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
-// `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row,
+// `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row | stamp16 << 16,
 // float bits of dy}, dx / dy = signed distance from the cell's anchor (its middle pixel); pixels that are not
 // inside an ordinary cell point at the extra row / column.
 struct WarpWork {
@@ -1773,7 +1793,7 @@ inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int f
     char *p = (char *)base;
     const size_t cells = (size_t)mesh_rows * mesh_cols;
     w.lut = (int *)p;
-    p += round256(((size_t)final_w + final_h) * sizeof(int));
+    p += round256(((size_t)final_w + final_h + 1) * sizeof(int));      // + the stamp word (warp_stamp)
     w.fcol = (unsigned *)p;
     p += round256((((size_t)final_w + 3) / 4 * 4) * sizeof(unsigned));
     w.frow = (uint2 *)p;
@@ -1909,6 +1929,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
     if (blockIdx.y != 0) return;
     const int row_blocks = (final_h + 1023) / 1024;
     const int b = blockIdx.x - inv_blocks;
+    if (b == 0 && tid == 0) lut[final_w + final_h] = warp_stamp(mesh_rows, mesh_cols, final_w, final_h);
     const bool is_row = b < row_blocks;
     const double *edges = is_row ? mesh_h : mesh_w;
     const int n_e = is_row ? n_h : n_w;
@@ -1953,7 +1974,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         const int rel = in ? d - span / 2 : 0;       // distance from the cell's anchor (its middle pixel), -127 ... 127
         const unsigned fd = (unsigned)(rel + 128);
         if (is_row) {
-            frow[idx] = make_uint2(fc, __float_as_uint((float)rel));
+            frow[idx] = make_uint2(fc | (warp_stamp16(mesh_rows, mesh_cols, final_w, final_h) << 16), __float_as_uint((float)rel));
         } else {
             fcol[idx] = fc | (fd << 16);
             // the pad up to a multiple of 4 columns repeats the last column (pixels past the row end are
@@ -2030,7 +2051,8 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
                                               const int *__restrict__ lut, int final_w, int final_h,
                                               int off_x, int off_y, uint8_t *__restrict__ out,
                                               const uint8_t *__restrict__ center, int center_h, int center_w,
-                                              int row_begin, int row_count, WarpStrides st) {
+                                              int row_begin, int row_count, WarpStrides st, int mesh_rows, int *status) {
+    if (!warp_tables_ready(lut[final_w + final_h], mesh_rows, mesh_cols, final_w, final_h, status)) return;
     // The launch covers canvas rows [row_begin, row_begin + row_count) - the whole canvas,
     // or one rank's band when a pair is sharded over GPUs; `out` points at the band's first row.
     // grid.z = pair of a batch (one mesh and canvas geometry, its own image, grid and canvas).
@@ -2161,7 +2183,8 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
                                                    const int *__restrict__ lut, int final_w, int final_h,
                                                    int off_x, int off_y, uint8_t *__restrict__ out,
                                                    const uint8_t *__restrict__ center, int center_h, int center_w,
-                                                   int row_begin, int row_count, WarpStrides st) {
+                                                   int row_begin, int row_count, WarpStrides st, int mesh_rows, int *status) {
+    if (!warp_tables_ready(lut[final_w + final_h], mesh_rows, mesh_cols, final_w, final_h, status)) return;
     // (Renumbering the blocks so that each XCD owns a band of rows was measured: no change.)
     {
         const long long pair = blockIdx.z;      // pair of a batch
@@ -2356,7 +2379,8 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
                                                    int final_w, int final_h, int off_x, int off_y,
                                                    uint8_t *__restrict__ out, const uint8_t *__restrict__ center,
-                                                   int center_h, int center_w, int row_begin, int row_count, WarpStrides st) {
+                                                   int center_h, int center_w, int row_begin, int row_count, WarpStrides st,
+                                                   int *status) {
     {
         const long long pair = blockIdx.z;      // pair of a batch: its own image, canvas, inverses and records
         img += pair * st.img;
@@ -2383,12 +2407,11 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
     const unsigned cev[4] = {ce.x, ce.y, ce.z, ce.w};
     unsigned col[4];
     float dxf[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        col[k] = cev[k] & 0xffffu;
-        dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
-    }
-    // row entries: wave-uniform, scalar loads
+    // row entries: wave-uniform, scalar loads; each carries the 16-bit stamp of the sizes the tables were built for.
+    // The tables' values become indices below: only if they were built for this mesh and canvas (warp_stamp16).  NOT an early
+    // exit - hipcc then sinks the column load below the branch, one more round trip in every wave's chain (+0.35 us at C3,
+    // measured) - and not a scalar load of its own (+0.25 us), but masks: on a foreign workspace every index becomes 0 (an
+    // ordinary cell: in bounds), nothing is stored, and the status word says so.
     unsigned rr[kRows];
     float dyf[kRows];
 #pragma unroll
@@ -2396,6 +2419,20 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         const uint2 e = frow[(unsigned)min(y_first + t, y_end - 1)];
         rr[t] = __builtin_amdgcn_readfirstlane(e.x);
         dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.y));
+    }
+#ifdef APAP_K3_ABL_NOSTAMP      // (A/B build: what the check costs)
+    const bool ready = true;
+#else
+    const bool ready = (rr[0] >> 16) == warp_stamp16(mesh_rows, mesh_cols, final_w, final_h);
+#endif
+    const unsigned cmask = ready ? 0xffffu : 0u;
+    if (!ready && lane == 0) atomicOr(status, apap::kStatusUnprepared);
+#pragma unroll
+    for (int t = 0; t < kRows; ++t) rr[t] &= cmask;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        col[k] = cev[k] & cmask;
+        dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
     APAP_K3_STAMP(1);       // column and row entries have arrived
     unsigned off[kRows][4];
@@ -2539,10 +2576,11 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
 #endif
     APAP_K3_STAMP(4);       // exact path done (if taken), gathers issued AND landed
+    const int y_store_end = ready ? y_end : y_first;     // a foreign workspace: no row is stored
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const int y = y_first + t;
-        if (y >= y_end) break;  // wave-uniform
+        if (y >= y_store_end) break;  // wave-uniform
         if (kBlend) {
             const int ci = y - off_y;
 #pragma unroll
@@ -2598,6 +2636,7 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
 // patched from a value read once per wave.  Per-pixel arithmetic, doubt rule and exact path are those of k_warp_fast.
 struct WalkGeo {
     WarpStrides st;
+    int *status;
     int img_h, img_w, mesh_rows, mesh_cols, final_w, final_h, off_x, off_y, center_h, center_w, row_begin, row_count;
     unsigned nbx;        // column blocks of 256 pixels per canvas row
     unsigned per, rem;   // wave-rows per wave: every wave takes `per`, the first `rem` waves one more
@@ -2725,6 +2764,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     unsigned u0 = gw * a.per + min(gw, a.rem);
     const unsigned u1 = u0 + a.per + (gw < a.rem ? 1u : 0u);
     if (u0 >= u1) return;
+    if (!warp_tables_ready(lut[a.final_w + a.final_h], a.mesh_rows, a.mesh_cols, a.final_w, a.final_h, a.status)) return;
     const unsigned img_bytes = (unsigned)a.img_h * (unsigned)a.img_w * 3u;
     const unsigned last_off = img_bytes - 3u;      // byte offset of the image's very last pixel
     const unsigned clast = kBlend ? (unsigned)a.center_h * (unsigned)a.center_w * 3u - 4u : 0u;
@@ -2782,7 +2822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
                 float dyf[S];
 #pragma unroll
                 for (int t = 0; t < S; ++t) {
-                    rr[t] = __builtin_amdgcn_readfirstlane(en[t].x);
+                    rr[t] = __builtin_amdgcn_readfirstlane(en[t].x) & 0xffffu;       // (the upper half is the tables' stamp)
                     dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(en[t].y));
                 }
                 y += S;
@@ -3369,6 +3409,7 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
         const unsigned waves = (unsigned)blocks * 4u;
         WalkGeo w;
         w.st = st;
+        w.status = a.status;
         w.img_h = img_h; w.img_w = img_w; w.mesh_rows = mesh_rows; w.mesh_cols = mesh_cols; w.final_w = final_w; w.final_h = final_h;
         w.off_x = off_x; w.off_y = off_y; w.center_h = center_h; w.center_w = center_w; w.row_begin = row_begin; w.row_count = row_count;
         w.nbx = nbx;
@@ -3401,11 +3442,11 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
     if (d_center)                                                                                                    \
         hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out, d_center,           \
-                           center_h, center_w, row_begin, row_count, st);                                            \
+                           center_h, center_w, row_begin, row_count, st, a.status);                                  \
     else                                                                                                             \
         hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
-                           (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st)
+                           (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st, a.status)
         if (rows == 4) { APAP_LAUNCH_FAST(4); }
         else if (rows == 8) { APAP_LAUNCH_FAST(8); }
         else { APAP_LAUNCH_FAST(2); }
@@ -3418,11 +3459,11 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
     if (d_center)                                                                                                    \
         hipLaunchKernelGGL((k_warp_rows<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols,  \
                            lut, final_w, final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin,      \
-                           row_count, st);                                                                                \
+                           row_count, st, mesh_rows, a.status);                                                      \
     else                                                                                                             \
         hipLaunchKernelGGL((k_warp_rows<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, \
                            lut, final_w, final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin,    \
-                           row_count, st)
+                           row_count, st, mesh_rows, a.status)
         if (rows == 4) { APAP_LAUNCH_ROWS(4); }
         else if (rows == 8) { APAP_LAUNCH_ROWS(8); }
         else { APAP_LAUNCH_ROWS(2); }
@@ -3432,10 +3473,12 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
         const dim3 grid((unsigned)((threads + 255) / 256), 1, batch);
         if (d_center)
             hipLaunchKernelGGL(k_warp<true>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin, row_count, st);
+                               final_h, off_x, off_y, d_out, d_center, center_h, center_w, row_begin, row_count, st, mesh_rows,
+                               a.status);
         else
             hipLaunchKernelGGL(k_warp<false>, grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_cols, lut, final_w,
-                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st);
+                               final_h, off_x, off_y, d_out, (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st, mesh_rows,
+                               a.status);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_warp_device launch");

@@ -526,7 +526,8 @@ def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=Fals
         kw = {"ctx": ctx} if ctx is not None else {}
         out, status = warp_fn(imgs, H, mesh_w, mesh_h, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols), **kw)
         if status is not None and int(status.cpu()[0]) != 0:
-            code = _native.ERR_SINGULAR if int(status.cpu()[0]) & 1 else _native.ERR_INDEX
+            word = int(status.cpu()[0])
+            code = _native.ERR_SINGULAR if word & 1 else _native.ERR_INDEX if word & 2 else _native.ERR_INVALID_ARG
             raise _native._ERROR_CLASSES[code](code, "warp_pairs: device status word %d" % int(status.cpu()[0]))
         canv = {k: out[i] for i, k in enumerate(mine)}
     if not gather:

@@ -316,6 +316,8 @@ class Pipeline:
                          "sync_and_download_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3}
         if status & 1:
             raise _native.ApapSingularError(_native.ERR_SINGULAR, "Singular matrix")
+        if status & 4:
+            raise _native.ApapValueError(_native.ERR_INVALID_ARG, "warp workspace without lookup tables for this geometry")
         if status & 2:
             raise _native.ApapIndexError(_native.ERR_INDEX, "index 0 is out of bounds for axis 0 with size 0 (mesh edges do not "
                                                              "cover the canvas)")

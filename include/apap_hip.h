@@ -319,7 +319,9 @@ int apap_warp_rows_device(apap_ctx *ctx, const uint8_t *d_img, int img_h, int im
  *   APAP_WARP_CELLS     per-cell inverses and the float32 estimate's records: depend on the H grids (and the edges);
  *   APAP_WARP_GATHER    K3, reading what the other two left in the workspace.
  * A caller that warps many grids over one geometry runs GEOMETRY once and CELLS | GATHER per grid; APAP_WARP_ALL is the
- * one-call form.  d_work: apap_warp_batch_workspace_bytes(...) bytes; the layout is private but stable between calls
+ * one-call form.  A GATHER on a workspace whose tables were never built, or were built for another mesh shape / canvas
+ * size, touches nothing and sets bit 2 (value 4) of *d_status (the tables carry a stamp of the sizes they were built for;
+ * bits 0 and 1 are the singular cell and the uncovered canvas of the reference's LinAlgError / IndexError).  d_work: apap_warp_batch_workspace_bytes(...) bytes; the layout is private but stable between calls
  * with equal (mesh_rows, mesh_cols, final_w, final_h, batch). */
 #define APAP_WARP_GEOMETRY 1
 #define APAP_WARP_CELLS 2

@@ -240,3 +240,56 @@ def test_solve_leaves_cells_warp_ready(native, cfg, batch):
     # the plan is reusable: a second solve overwrites the cells, the geometry stays
     H_a2 = a.solve(tables.flip(0).contiguous(), denorms.flip(0).contiguous(), vert, p0.gamma, p0.sigma)
     assert torch.equal(a.gather(imgs.flip(0).contiguous()).flip(0), out_a) and torch.equal(H_a2.view(batch, -1, 9).flip(0), H_a.view(batch, -1, 9))
+
+
+def test_gather_on_an_unprepared_workspace_reports_and_touches_nothing(native):
+    """A gather on a workspace whose lookup tables were never built (zeroed or full of garbage), or were built for another mesh
+    shape or canvas size, must not use the tables' values as indices: the canvas stays untouched and bit 2 of the status word is
+    set, in every kernel form (the tables carry a stamp of the sizes they were built for)."""
+    import torch
+    from cvx_proj_amd import dist as D
+    from cvx_proj_amd.synth import synth_pair
+    dev = torch.device("cuda", 0)
+    p = synth_pair(640, 400, 200, 12, seed=3)
+    rows, cols = p.vertices.shape[:2]
+    H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+    ref, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    img = torch.from_numpy(p.img).to(dev)
+    Hd = torch.from_numpy(H.reshape(-1, 9)).to(dev)
+    forms = [dict(), dict(warp_rows=2), dict(warp_rows=8), dict(warp_fast=0), dict(warp_rows=0), dict(warp_walk=1), dict(warp_walk=1, warp_stage=2)]
+    for opts in forms:
+        ctx = native.Context(**opts)
+        try:
+            plan = D.WarpPlan(p.mesh, (rows, cols), p.final_w, p.final_h, p.off_x, p.off_y, dev, ctx=ctx)
+            plan.cells(Hd)
+            good = plan.work.clone()
+            out = torch.full((1, p.final_h, p.final_w, 3), 7, dtype=torch.uint8, device=dev)
+            plan.gather(img, out=out)
+            assert int(plan.status.cpu()[0]) == 0 and np.array_equal(out[0].cpu().numpy(), ref), opts
+            for what in ("zeros", "garbage", "other canvas", "other mesh"):
+                if what == "zeros":
+                    plan.work.zero_()
+                elif what == "garbage":
+                    plan.work.copy_(torch.randint(0, 256, plan.work.shape, dtype=torch.uint8, device=dev))
+                else:
+                    plan.work.copy_(good)
+                if what == "other canvas":        # tables of a canvas one row shorter, in the same (large enough) workspace
+                    other = D.WarpPlan(p.mesh, (rows, cols), p.final_w, p.final_h - 1, p.off_x, p.off_y, dev, ctx=ctx)
+                    plan.work[:other.work.numel()].copy_(other.work)
+                if what == "other mesh":
+                    m2 = np.stack([p.mesh[0][:-1], p.mesh[1][:-1]])
+                    m2[:, -1] = p.mesh[:, -1]
+                    other = D.WarpPlan(m2, (rows - 1, cols - 1), p.final_w, p.final_h, p.off_x, p.off_y, dev, ctx=ctx)
+                    plan.work[:other.work.numel()].copy_(other.work)
+                plan.status.zero_()
+                out.fill_(7)
+                plan.gather(img, out=out)
+                torch.cuda.synchronize()
+                assert int(plan.status.cpu()[0]) == 4, (opts, what)
+                assert bool((out == 7).all()), (opts, what)
+            plan.work.copy_(good)                 # and the prepared tables still serve
+            plan.status.zero_()
+            plan.gather(img, out=out)
+            assert int(plan.status.cpu()[0]) == 0 and np.array_equal(out[0].cpu().numpy(), ref), opts
+        finally:
+            ctx.close()
