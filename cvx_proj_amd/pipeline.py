@@ -20,7 +20,6 @@ torch is used for device memory and the stream only.  No CPU fallback.
 from __future__ import annotations
 
 import ctypes
-import os
 
 import numpy as np
 
@@ -161,7 +160,7 @@ class Pipeline:
         torch, lib = self.torch, _native.lib()
         t0 = time.perf_counter()
         early = None
-        trace = self.trace or "events" in os.environ.get("APAP_PIPE_EXP", "")
+        trace = self.trace
         pinned_in = other_img is not None and self._is_pinned(other_img) and (center_img is None or self._is_pinned(center_img))
 
         def start_image_upload():

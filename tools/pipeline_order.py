@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Pipeline.run_pair on C3 with the image and the canvas in page-locked arrays: median wall clock of 40 passes (APAP_PIPE_EXP picks the
-experimental orderings), canvas checked against a pageable pass."""
+"""Pipeline.run_pair on C3 with the image and the canvas in page-locked arrays: median wall clock of 40 passes, canvas checked against a
+pageable pass; APAP_PIPE_EXP=events adds three passes with HIP events at the stage boundaries (Pipeline.trace).  (Round 4 also ran it
+with experimental orderings - solve first, an own main stream - that are no longer in the pipeline: profiles/r04_pipeline_overlap.txt.)"""
 import contextlib
 import io
 import os
@@ -15,6 +16,7 @@ from cvx_proj_amd.synth import config_pair  # noqa: E402
 p = config_pair("C3")
 m = p.vertices.shape[0]
 pipe = Pipeline()
+pipe.trace = "events" in os.environ.get("APAP_PIPE_EXP", "")
 img = pipe.pinned_array(p.img.shape)
 np.copyto(img, p.img)
 canvas = pipe.pinned_array((p.final_h, p.final_w, 3))
