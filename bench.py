@@ -27,9 +27,21 @@ the path shards and puts both in the one JSON line:
   scaling.  At N = 1 it is the single-GPU baseline of that curve.
 
 Further objects: ``roofline`` for the dominant kernel (K1, timed live with HIP events on the launch
-stream), ``call_level`` (numpy in -> numpy out through the host-buffer entry points: host set-up,
-PCIe and synchronisation included) and ``cpu_baseline`` (the oracle's faithful-loop numpy port on
-this host: 1 thread, default BLAS threads, all usable cores).
+stream); ``roofline_warp`` / ``roofline_warp_cold`` for K3 on the headline canvas (launches back to back,
+source and canvas warm / rotated through 640 MB), ``cells.roofline_warp`` for the same kernel on the
+cells configuration's canvas and ``pairs.warp.roofline`` for the batched warp of config 5; ``standalone``
+(the solve and the warp as calls of their own, without the warp-ready tail / with the set-up launch);
+``call_level`` (numpy in -> numpy out through the host-buffer entry points: host set-up, PCIe and
+synchronisation included); ``pipeline`` (apap.py's __main__ as one resident pass: from ordinary numpy
+arrays, from page-locked ones, and as the reference's chain of calls) and ``cpu_baseline`` (the oracle's
+faithful-loop numpy port on this host: 1 thread, default BLAS threads, all usable cores).
+
+Multi-rank runs: a 120 s collective timeout, a tiny first collective and a phase marker on stderr before
+every phase; a failure ends in a non-zero exit code with ``bench_failed`` on stderr.
+``APAP_BENCH_BACKEND=gloo`` rehearses more ranks than GPUs; ``APAP_BENCH_FORCE_GROUP=1`` (with RANK=0,
+WORLD_SIZE=1, MASTER_ADDR / MASTER_PORT) runs ONE rank through an ``nccl`` group and every collective
+of the multi-rank paths - first contact with RCCL on a one-GPU box; ``APAP_BENCH_SELFTEST=1`` is the
+launch + rendezvous + one collective without a GPU.
 """
 import os
 
