@@ -2372,8 +2372,26 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
 #ifndef APAP_K3_WAVES_ATTR
 #define APAP_K3_WAVES_ATTR
 #endif
+#ifndef APAP_K3_PRIO
+#define APAP_K3_PRIO 0
+#endif
+#ifndef APAP_K3_LDSREC
+#define APAP_K3_LDSREC 0
+#endif
+#ifndef APAP_K3_XCD
+#define APAP_K3_XCD 0
+#endif
+#ifndef APAP_K3_A16
+#define APAP_K3_A16 0
+#endif
+#ifndef APAP_K3_NT
+#define APAP_K3_NT 1
+#endif
+#ifndef APAP_K3_BLOCK
+#define APAP_K3_BLOCK 256
+#endif
 template <bool kBlend, int kRows>
-__global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
+__global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
                                                    const double *__restrict__ hinv_pad, int mesh_rows, int mesh_cols,
                                                    const int *__restrict__ lut, const float4 *__restrict__ frec,
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
@@ -2392,11 +2410,42 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef APAP_K3_TRACE
-    const unsigned k3_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (unsigned)wave;
+    const unsigned k3_id = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
     APAP_K3_STAMP(0);
 #endif
-    const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
-    const int y_first = row_begin + ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * kRows;
+#if APAP_K3_PRIO
+    {
+        // the wave's slot on its SIMD (HW_REG_HW_ID bits 3:0) picks its issue priority
+        const unsigned slot = (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
+        if (APAP_K3_PRIO >= 4) {        // stagger: some of a SIMD's waves start late
+            if (APAP_K3_PRIO == 4 && (slot & 1u)) __builtin_amdgcn_s_sleep(40);
+            if (APAP_K3_PRIO == 5 && (slot & 1u)) __builtin_amdgcn_s_sleep(80);
+            if (APAP_K3_PRIO == 6) {
+                if (slot & 1u) __builtin_amdgcn_s_sleep(16);
+                if (slot & 2u) __builtin_amdgcn_s_sleep(32);
+                if (slot & 4u) __builtin_amdgcn_s_sleep(64);
+            }
+        } else {
+        const unsigned p = APAP_K3_PRIO == 1 ? (slot & 3u) : APAP_K3_PRIO == 2 ? ((slot >> 1) & 3u) : (slot & 1u) * 3u;
+        if (p == 1u) __builtin_amdgcn_s_setprio(1);
+        else if (p == 2u) __builtin_amdgcn_s_setprio(2);
+        else if (p == 3u) __builtin_amdgcn_s_setprio(3);
+        }
+    }
+#endif
+    // tile of this workgroup: 256 canvas columns x (waves x kRows) rows.
+#if APAP_K3_XCD
+    // The launch is one-dimensional and workgroup L runs on XCD L % 8 (each XCD has its own L2): the column blocks of one
+    // strip-row - neighbours that share the cache lines at their common edges, in the canvas and in the source - all go
+    // to the XCD (L % 8), consecutive strip-rows to consecutive XCDs.  (A two-dimensional grid deals the 16 column blocks of a
+    // C3 strip-row over all eight L2s: every edge line written in two halves by two L2s.)
+    const int nbx = (final_w + 255) >> 8;
+    const int bid_x = (int)(blockIdx.x >> 3) % nbx, bid_y = ((int)(blockIdx.x >> 3) / nbx) * 8 + (int)(blockIdx.x & 7u);
+#else
+    const int bid_x = blockIdx.x, bid_y = blockIdx.y;
+#endif
+    const int j0 = (bid_x * 64 + lane) * 4;
+    const int y_first = row_begin + (bid_y * (int)(blockDim.x >> 6) + wave) * kRows;
     const int y_end = min(y_first + kRows, row_begin + row_count);
     if (j0 >= final_w || y_first >= y_end) return;
     const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
@@ -2434,6 +2483,33 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         col[k] = cev[k] & cmask;
         dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
+#if APAP_K3_LDSREC
+    // the cell records through LDS: a wave-row of 256 pixels meets a handful of cells, yet every lane used to fetch two
+    // 48-byte records per pass through the vector memory path (6 x 1 KiB of returned data per pass against 4 KiB of source
+    // pixels per strip), and only after its column entries had come back.  The wave's FIRST cell column comes from a scalar
+    // load of the column table instead, lanes 0-15 / 16-31 fetch the 16 records from there on of the strip's first / last
+    // cell row (in flight together with the lane's own column entries) and leave them in a wave-private LDS block; a pass
+    // reads its two records from there.  Strips that meet more than 16 cell columns or more than 2 cell rows (meshes finer
+    // than the strip), or whose cell columns do not ascend (irregular meshes), and the canvas's last, partly filled column
+    // block keep the direct loads.
+    __shared__ float4 s_rec[APAP_K3_BLOCK / 64][32][3];
+    const unsigned c_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(fcol[(unsigned)bid_x * 256u] & cmask));
+    {
+        const unsigned rsel = lane < 16 ? rr[0] : rr[kRows - 1];
+        const unsigned csel = min(c_lo + ((unsigned)lane & 15u), (unsigned)mesh_cols);
+        if (lane < 32) {
+            const float4 *pr = frec + (size_t)(rsel * (unsigned)(mesh_cols + 1) + csel) * 3;
+            const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
+            s_rec[wave][lane][0] = r0;
+            s_rec[wave][lane][1] = r1;
+            s_rec[wave][lane][2] = r2;
+        }
+    }
+    bool rec_lds = bid_x * 256 + 128 <= final_w;      // lanes 0-31 are all alive (they fetched the records)
+#pragma unroll
+    for (int t = 1; t + 1 < kRows; ++t) rec_lds = rec_lds && (rr[t] == rr[0] || rr[t] == rr[kRows - 1]);
+    rec_lds = rec_lds && __builtin_amdgcn_ballot_w64((col[0] - c_lo > 15u) | (col[3] - c_lo > 15u)) == 0ull;
+#endif
     APAP_K3_STAMP(1);       // column and row entries have arrived
     unsigned off[kRows][4];
     unsigned int px[kRows][4];
@@ -2459,8 +2535,20 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
 #pragma unroll
         for (int t = 1; t < kRows; ++t) r = (t == first) ? rr[t] : r;
         const unsigned base = r * rec_stride;
+#if APAP_K3_LDSREC
+        float4 a0, a1, a2, b0, b1, b2;
+        if (rec_lds) {
+            const float4 *q = s_rec[wave][r == rr[0] ? 0 : 16];
+            const float4 *qa = q + (col[0] - c_lo) * 3u, *qb = q + (col[3] - c_lo) * 3u;
+            a0 = qa[0]; a1 = qa[1]; a2 = qa[2]; b0 = qb[0]; b1 = qb[1]; b2 = qb[2];
+        } else {
+            const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
+            a0 = pa[0]; a1 = pa[1]; a2 = pa[2]; b0 = pb[0]; b1 = pb[1]; b2 = pb[2];
+        }
+#else
         const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
         const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
+#endif
         APAP_K3_STAMP(2);   // the records of this pass have arrived (the last pass's stamp stays)
         // per pixel: x-dependent parts of the three sums, the y coefficients, anchor, window
         float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
@@ -2577,6 +2665,17 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
 #endif
     APAP_K3_STAMP(4);       // exact path done (if taken), gathers issued AND landed
     const int y_store_end = ready ? y_end : y_first;     // a foreign workspace: no row is stored
+#if APAP_K3_A16
+    // A wave-row is 768 consecutive canvas bytes that start at ANY byte (a canvas row is 3 final_w bytes): sixty-four
+    // unaligned 12-byte stores per row.  Full wave-rows go through a wave-private LDS block instead - every lane leaves its
+    // 12 bytes there, lanes 0-47 take back one 16-byte piece each, cut at the 16-byte boundaries of the canvas ADDRESS (a
+    // wave-uniform byte shift: one v_alignbyte per dword), and store it aligned; the up to 15 bytes before the first and after the
+    // last boundary go out in one byte store (lanes 0-15 / 16-31).  The canvas's last, partly filled column block keeps the 12-byte stores.
+    __shared__ __attribute__((aligned(16))) unsigned s_row[APAP_K3_BLOCK / 64][kRows][196];
+    const bool full_row = bid_x * 256 + 256 <= final_w;
+#else
+    const bool full_row = false;
+#endif
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const int y = y_first + t;
@@ -2601,12 +2700,47 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
 #ifdef APAP_K3_ABL_NOSTORE
         if ((px[t][0] ^ px[t][1] ^ px[t][2] ^ px[t][3]) != 0x12345678u) continue;   // never true for 24-bit pixels
 #endif
+#if APAP_K3_A16
+        if (full_row) {
+            unsigned *mine = s_row[wave][t];
+            mine[3 * lane] = px[t][0] | (px[t][1] << 24);
+            mine[3 * lane + 1] = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
+            mine[3 * lane + 2] = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
+            uint8_t *row = out + ((size_t)(y - row_begin) * (size_t)final_w + (size_t)(bid_x * 256)) * 3;
+            const unsigned head = (unsigned)__builtin_amdgcn_readfirstlane((int)((0u - (unsigned)(uintptr_t)row) & 15u));
+            const unsigned pieces = (768u - head) >> 4, tail = (768u - head) & 15u;
+            if ((unsigned)lane < pieces) {
+                const unsigned *q = mine + (head >> 2) + 4u * (unsigned)lane;
+                const unsigned v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], sh = head & 3u;
+                uint4 piece;
+                piece.x = __builtin_amdgcn_alignbyte(v1, v0, sh);
+                piece.y = __builtin_amdgcn_alignbyte(v2, v1, sh);
+                piece.z = __builtin_amdgcn_alignbyte(v3, v2, sh);
+                piece.w = __builtin_amdgcn_alignbyte(v4, v3, sh);
+                *reinterpret_cast<uint4 *>(row + head + 16u * (unsigned)lane) = piece;
+            }
+            const unsigned bi = lane < 16 ? (unsigned)lane : 768u - tail + (unsigned)(lane - 16);
+            const bool edge = lane < 16 ? (unsigned)lane < head : (unsigned)(lane - 16) < tail;
+            if (lane < 32 && edge) row[bi] = reinterpret_cast<const uint8_t *>(mine)[bi];
+            continue;
+        }
+#endif
         if (npx == 4) {
+#if APAP_K3_NT
+            // non-temporal: the canvas is written once and never read back here - the bytes stream past the L2 instead of
+            // waiting in it, dirty, for the write-back at the end of the kernel
+            typedef unsigned Dwords3 __attribute__((ext_vector_type(3)));
+            typedef Dwords3 Dwords3AnyByte __attribute__((aligned(1)));
+            const Dwords3 v = {px[t][0] | (px[t][1] << 24), __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u),
+                               __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u)};
+            __builtin_nontemporal_store(v, reinterpret_cast<Dwords3AnyByte *>(o));
+#else
             Bytes12 v;
             v.a = px[t][0] | (px[t][1] << 24);
             v.b = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
             v.c = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
             __builtin_memcpy(o, &v, 12);
+#endif
         } else {
             for (int k = 0; k < npx; ++k) {
                 o[3 * k] = (uint8_t)(px[t][k] & 0xff);
@@ -3437,7 +3571,12 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
 #define APAP_K3_BLOCK 256
 #endif
         constexpr int kWpb = APAP_K3_BLOCK / 64;      // waves (= strips) per block
+#if APAP_K3_XCD
+        // one-dimensional: the kernel deals the tiles over the XCDs itself (strip-rows rounded up to a multiple of 8)
+        const dim3 grid((unsigned)((final_w + 255) / 256) * (unsigned)(((row_count + kWpb * rows - 1) / (kWpb * rows) + 7) / 8 * 8), 1, batch);
+#else
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + kWpb * rows - 1) / (kWpb * rows)), batch);
+#endif
 #define APAP_LAUNCH_FAST(R)                                                                                          \
     if (d_center)                                                                                                    \
         hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
