@@ -618,10 +618,6 @@ def main():
     ap.add_argument("--want-waves", type=int, help="tuning: APAP_OPT_WANT_WAVES of the context (K1 keypoint splits)")
     ap.add_argument("--warp-rows", type=int, choices=[0, 2, 4, 8], help="tuning: APAP_OPT_WARP_ROWS (0 = flat-order warp kernel)")
     ap.add_argument("--warp-fast", type=int, choices=[0, 1], help="tuning: APAP_OPT_WARP_FAST (0 = float64 for every pixel of K3)")
-    ap.add_argument("--warp-walk", type=int, choices=[0, 1], help="K3 form: 1 = persistent column-walk kernel, 0 = one strip per wave")
-    ap.add_argument("--warp-waves", type=int, help="tuning, walk form: resident waves per CU")
-    ap.add_argument("--warp-stage", type=int, choices=[1, 2], help="tuning, walk form: rows per pipeline stage")
-    ap.add_argument("--warp-min-run", type=int, help="tuning, walk form: least rows per wave on small canvases")
     ap.add_argument("--fused-max-cells", type=int, help="tuning: APAP_OPT_FUSED_MAX_CELLS (fused K1 + K2 launch for small meshes)")
     ap.add_argument("--cold-mb", type=float, default=640.0,
                     help="cold-cache warp leg: rotate over this many MB of (image, canvas) copies (0 = skip)")
@@ -687,9 +683,6 @@ def main():
         ctx.set("fused_max_cells", a.fused_max_cells)
     if a.warp_fast is not None:
         ctx.set("warp_fast", a.warp_fast)
-    for name in ("warp_walk", "warp_waves", "warp_stage", "warp_min_run"):
-        if getattr(a, name) is not None:
-            ctx.set(name, getattr(a, name))
     stream = torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -1063,7 +1056,7 @@ def main():
             traffic = tj.get(f"{a.config}:k_assemble_{resolved}")
             traffic_warp = tj.get(f"{a.config}:k_warp_fast", tj.get(f"{a.config}:k_warp_rows"))
         # K3 (HBM-bound half of the metric): 6 B per in-range pixel, 3 B per blank one
-        k3_name = "k_warp_walk" if ctx.get("warp_walk") else "k_warp_fast"
+        k3_name = "k_warp_fast"
         out_pixels = pair.final_w * pair.final_h
         nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu())
         warp_bytes = 6 * nz + 3 * (out_pixels - nz)

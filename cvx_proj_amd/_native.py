@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("APAP_HIP_LIB") or os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
-ABI_VERSION = 4          # APAP_ABI_VERSION of include/apap_hip.h
+ABI_VERSION = 5          # APAP_ABI_VERSION of include/apap_hip.h
 # kernel slots of apap_ctx_profile_read (include/apap_hip.h)
 PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply", "ransac")
 PROF_SLOTS = len(PROF_NAMES)
@@ -28,8 +28,7 @@ VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1,
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 # options of a context (include/apap_hip.h)
 OPT_SOLVER_VARIANT, OPT_EIGEN_SOLVER, OPT_CAREFUL, OPT_PROFILE, OPT_WANT_WAVES, OPT_WARP_ROWS, OPT_WEIGHT_CHUNK_KB, \
-    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS, OPT_WARP_WALK, OPT_WARP_WAVES, OPT_WARP_STAGE, \
-    OPT_WARP_MIN_RUN = range(15)
+    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS = range(11)
 
 
 class ApapError(RuntimeError):
@@ -81,11 +80,17 @@ SIGNATURES = {
     "apap_ctx_profile_read": (C.c_int, [_vp, _f32p, _i32p]),
     "apap_host_prepare": (C.c_int, [_f32p, _f32p, C.c_int] + [_f32p] * 10),
     "apap_host_dlt_rows": (C.c_int, [_f32p, _f32p, C.c_int, _f32p]),
+    "apap_host_prepare_pts": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int] + [_f32p] * 6 + [_f64p] * 4),
+    "apap_host_dlt_rows_pts": (C.c_int, [_f64p, _f64p, C.c_int, C.c_int, _f32p]),
+    "apap_host_build_table_rows": (C.c_int, [_f64p, _f32p, C.c_int, _f64p]),
     "apap_host_build_table": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, _f64p]),
     "apap_host_build_denorm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f64p]),
     "apap_local_homography": (C.c_int, [_vp, _f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
                                         C.c_double, _f32p, _f64p, C.c_int]),
     "apap_local_weights": (C.c_int, [_vp, _f32p, C.c_int, _f64p, C.c_int, C.c_double, C.c_double, _f64p, C.c_int]),
+    "apap_local_homography_pts": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
+                                            C.c_double, _f32p, _f64p, C.c_int]),
+    "apap_local_weights_pts": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _f64p, C.c_int, C.c_double, C.c_double, _f64p, C.c_int]),
     "apap_local_warp": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, _f32p, C.c_int]),
     "apap_local_warp_f64": (C.c_int, [_vp, _u8p, C.c_int, C.c_int, _f64p, C.c_int, C.c_int, _f64p, C.c_int, _f64p,
@@ -189,8 +194,7 @@ class Context:
     _NAMES = {"variant": OPT_SOLVER_VARIANT, "eigen": OPT_EIGEN_SOLVER, "careful": OPT_CAREFUL, "profile": OPT_PROFILE,
               "want_waves": OPT_WANT_WAVES, "warp_rows": OPT_WARP_ROWS, "weight_chunk_kb": OPT_WEIGHT_CHUNK_KB,
               "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST, "overlap_pcie": OPT_OVERLAP_PCIE,
-              "plan_cells": OPT_PLAN_CELLS, "warp_walk": OPT_WARP_WALK, "warp_waves": OPT_WARP_WAVES, "warp_stage": OPT_WARP_STAGE,
-              "warp_min_run": OPT_WARP_MIN_RUN}
+              "plan_cells": OPT_PLAN_CELLS}
 
     def set(self, name, value):
         check(lib().apap_ctx_set_option(self._h, self._NAMES[name], int(value)))
@@ -246,29 +250,58 @@ def as_f32(a, shape_tail=None):
     return a
 
 
+def as_points(a):
+    """Keypoints in the dtype the reference would compute with: float32 stays float32 (what utils.get_features returns),
+    everything else - float64, float16, integers - is taken as float64 (numpy's own reductions promote integers to float64;
+    nothing in apap.py:35-100 casts its argument).  Returns (contiguous (n, 2) array, is_float64)."""
+    a = np.asarray(a)
+    a = np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
+    if a.shape[-1:] != (2,):
+        raise ValueError(f"expected trailing shape (2,), got {a.shape}")
+    return a, int(a.dtype == np.float64)
+
+
+def _vptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
 # ------------------------------------------------------------------ host-only helpers
 def host_prepare(src, dst):
-    """C restatement of the set-up in apap.py:132-140,165-166.  Returns a dict of
-    float32 arrays: N1 N2 C1 C2 iC2 iN2 (3x3) and nf1 nf2 cf1 cf2 (n x 2)."""
-    src = as_f32(src, (2,))
-    dst = as_f32(dst, (2,))
+    """C restatement of the set-up in apap.py:132-140,165-166, in the dtype of each keypoint set.  Returns a dict: N1 N2 C1 C2
+    iC2 iN2 (3x3 float32) and nf1 nf2 cf1 cf2 (n x 2; float32 for a float32 set, float64 for a float64 one)."""
+    src, s64 = as_points(src)
+    dst, d64 = as_points(dst)
     if src.shape != dst.shape or src.ndim != 2:
         raise ValueError(f"src/dst must both be (n, 2); got {src.shape} and {dst.shape}")
     n = src.shape[0]
     out = {k: np.empty((3, 3), np.float32) for k in ("N1", "N2", "C1", "C2", "iC2", "iN2")}
-    out.update({k: np.empty((n, 2), np.float32) for k in ("nf1", "nf2", "cf1", "cf2")})
-    check(lib().apap_host_prepare(_ptr(src, C.c_float), _ptr(dst, C.c_float), n,
-                                  *[_ptr(out[k], C.c_float) for k in
-                                    ("N1", "N2", "C1", "C2", "iC2", "iN2", "nf1", "nf2", "cf1", "cf2")]))
+    if not s64 and not d64:
+        out.update({k: np.empty((n, 2), np.float32) for k in ("nf1", "nf2", "cf1", "cf2")})
+        check(lib().apap_host_prepare(_ptr(src, C.c_float), _ptr(dst, C.c_float), n,
+                                      *[_ptr(out[k], C.c_float) for k in
+                                        ("N1", "N2", "C1", "C2", "iC2", "iN2", "nf1", "nf2", "cf1", "cf2")]))
+        return out
+    wide = {k: np.empty((n, 2), np.float64) for k in ("nf1", "nf2", "cf1", "cf2")}
+    check(lib().apap_host_prepare_pts(_vptr(src), s64, _vptr(dst), d64, n,
+                                      *[_ptr(out[k], C.c_float) for k in ("N1", "N2", "C1", "C2", "iC2", "iN2")],
+                                      *[_ptr(wide[k], C.c_double) for k in ("nf1", "nf2", "cf1", "cf2")]))
+    for k, is64 in (("nf1", s64), ("cf1", s64), ("nf2", d64), ("cf2", d64)):
+        out[k] = wide[k] if is64 else wide[k].astype(np.float32)        # exact: the values ARE float32
     return out
 
 
 def host_dlt_rows(cf1, cf2):
-    cf1 = as_f32(cf1, (2,))
-    cf2 = as_f32(cf2, (2,))
+    """APAP.matrix_generate (apap.py:103-119): float32 rows; a float64 operand makes the products float64 products rounded
+    once on the store, two float32 operands float32 products."""
+    cf1, a64 = as_points(cf1)
+    cf2, b64 = as_points(cf2)
     n = cf1.shape[0]
     aa = np.empty((2 * n, 9), np.float32)
-    check(lib().apap_host_dlt_rows(_ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n, _ptr(aa, C.c_float)))
+    if not a64 and not b64:
+        check(lib().apap_host_dlt_rows(_ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n, _ptr(aa, C.c_float)))
+    else:
+        cf1, cf2 = np.ascontiguousarray(cf1, np.float64), np.ascontiguousarray(cf2, np.float64)
+        check(lib().apap_host_dlt_rows_pts(_ptr(cf1, C.c_double), _ptr(cf2, C.c_double), n, 1, _ptr(aa, C.c_float)))
     return aa
 
 
@@ -282,13 +315,18 @@ def _out_f64(out, shape):
 
 
 def host_build_table(src, cf1, cf2, out=None):
-    src = as_f32(src, (2,))
-    cf1 = as_f32(cf1, (2,))
-    cf2 = as_f32(cf2, (2,))
+    src, s64 = as_points(src)
+    cf1, a64 = as_points(cf1)
+    cf2, b64 = as_points(cf2)
     n = src.shape[0]
     table = _out_f64(out, (n, TABLE_STRIDE))
-    check(lib().apap_host_build_table(_ptr(src, C.c_float), _ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n,
-                                      _ptr(table, C.c_double)))
+    if not (s64 or a64 or b64):
+        check(lib().apap_host_build_table(_ptr(src, C.c_float), _ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n,
+                                          _ptr(table, C.c_double)))
+    else:       # from the DLT rows themselves and the source keypoints as float64
+        aa = host_dlt_rows(cf1, cf2)
+        src = np.ascontiguousarray(src, np.float64)
+        check(lib().apap_host_build_table_rows(_ptr(src, C.c_double), _ptr(aa, C.c_float), n, _ptr(table, C.c_double)))
     return table
 
 
@@ -301,8 +339,8 @@ def host_build_denorm(iC2, C1, iN2, N1, out=None):
 
 # ---------------------------------------------------------------- host-buffer compute
 def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device=-1, ctx=None):
-    src = as_f32(src, (2,))
-    dst = as_f32(dst, (2,))
+    src, s64 = as_points(src)
+    dst, d64 = as_points(dst)
     if src.ndim != 2 or src.shape != dst.shape:
         raise ValueError(f"src/dst must both be (n, 2); got {src.shape} and {dst.shape}")
     vertices = np.ascontiguousarray(vertices, dtype=np.float64)
@@ -312,24 +350,24 @@ def local_homography(src, dst, vertices, gamma, sigma, want_weights=True, device
     n = src.shape[0]
     H = np.empty((rows, cols, 3, 3), np.float32)
     W = np.empty((rows, cols, n), np.float64) if want_weights else None
-    check(lib().apap_local_homography(_h(ctx), _ptr(src, C.c_float), _ptr(dst, C.c_float), n, _ptr(vertices, C.c_double),
-                                      rows, cols, float(gamma), float(sigma), _ptr(H, C.c_float),
-                                      _ptr(W, C.c_double), device))
+    check(lib().apap_local_homography_pts(_h(ctx), _vptr(src), s64, _vptr(dst), d64, n, _ptr(vertices, C.c_double),
+                                          rows, cols, float(gamma), float(sigma), _ptr(H, C.c_float),
+                                          _ptr(W, C.c_double), device))
     return H, W
 
 
 def local_weights(src, points, gamma, sigma, device=-1, ctx=None):
     """``max(exp(-|p - s| / sigma^2), gamma)`` for every (sample point p, keypoint s): ``points`` (..., 2) float64
     -> (..., n) float64.  The weights of reference apap.py:150-153 for any subset of the mesh."""
-    src = as_f32(src, (2,))
+    src, s64 = as_points(src)
     pts = np.ascontiguousarray(points, dtype=np.float64)
     if pts.shape[-1:] != (2,):
         raise ValueError(f"points must be (..., 2); got {pts.shape}")
     n, cells = src.shape[0], pts.size // 2
     W = np.empty(pts.shape[:-1] + (n,), np.float64)
     if cells:
-        check(lib().apap_local_weights(_h(ctx), _ptr(src, C.c_float), n, _ptr(pts, C.c_double), cells, float(gamma),
-                                       float(sigma), _ptr(W, C.c_double), device))
+        check(lib().apap_local_weights_pts(_h(ctx), _vptr(src), s64, n, _ptr(pts, C.c_double), cells, float(gamma),
+                                           float(sigma), _ptr(W, C.c_double), device))
     return W
 
 

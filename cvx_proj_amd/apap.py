@@ -42,7 +42,7 @@ class LazyWeights:
     dtype = np.dtype(np.float64)
 
     def __init__(self, src, vertices, gamma, sigma, device=-1, ctx=None):
-        self._src = _native.as_f32(src, (2,)).copy()
+        self._src = _native.as_points(src)[0].copy()      # float32 stays float32, anything else float64 (apap.py:150)
         self._vertices = np.array(vertices, dtype=np.float64)       # a copy: the caller may reuse its buffer
         self._par = (float(gamma), float(sigma), device, ctx)
         self._full = None

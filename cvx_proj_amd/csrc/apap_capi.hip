@@ -145,6 +145,11 @@ static int stream_weights(apap_ctx *ctx, apap_ctx *pool, int dev, const void *d_
 
 int apap_local_weights(apap_ctx *ctx, const float *src, int n, const double *vertices, int cells, double gamma,
                        double sigma, double *W_out, int device) {
+    return apap_local_weights_pts(ctx, src, 0, n, vertices, cells, gamma, sigma, W_out, device);
+}
+
+int apap_local_weights_pts(apap_ctx *ctx, const void *src, int src_f64, int n, const double *vertices, int cells, double gamma,
+                           double sigma, double *W_out, int device) {
     if (!src || !vertices || !W_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_weights: null argument");
     if (n < 1 || cells < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_weights: n=%d cells=%d", n, cells);
     PoolLock pl(ctx);
@@ -154,8 +159,8 @@ int apap_local_weights(apap_ctx *ctx, const float *src, int n, const double *ver
     // the weight kernel reads a keypoint's (x, y) from columns 30, 31 of its table row
     std::vector<double> table((size_t)n * APAP_TABLE_STRIDE, 0.0);
     for (int k = 0; k < n; ++k) {
-        table[(size_t)k * APAP_TABLE_STRIDE + 30] = (double)src[2 * k];
-        table[(size_t)k * APAP_TABLE_STRIDE + 31] = (double)src[2 * k + 1];
+        table[(size_t)k * APAP_TABLE_STRIDE + 30] = src_f64 ? ((const double *)src)[2 * k] : (double)((const float *)src)[2 * k];
+        table[(size_t)k * APAP_TABLE_STRIDE + 31] = src_f64 ? ((const double *)src)[2 * k + 1] : (double)((const float *)src)[2 * k + 1];
     }
     const SyncOnExit drain;   // the async copy below reads `table`
     void *d_table, *d_vert;
@@ -169,6 +174,12 @@ int apap_local_weights(apap_ctx *ctx, const float *src, int n, const double *ver
 int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int n, const double *vertices,
                           int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
                           double *W_out, int device) {
+    return apap_local_homography_pts(ctx, src, 0, dst, 0, n, vertices, mesh_rows, mesh_cols, gamma, sigma, H_out, W_out, device);
+}
+
+int apap_local_homography_pts(apap_ctx *ctx, const void *src, int src_f64, const void *dst, int dst_f64, int n,
+                              const double *vertices, int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
+                              double *W_out, int device) {
     if (!src || !dst || !vertices || !H_out) return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: null argument");
     if (n < 2 || mesh_rows < 1 || mesh_cols < 1)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_local_homography: n=%d mesh=%dx%d", n, mesh_rows, mesh_cols);
@@ -179,13 +190,18 @@ int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int
     if (rc) return rc;
 
     // once-per-pair set-up on the host (apap.py:132-145)
+    // in the dtype of each keypoint set, as the reference's own functions run (float64 keypoints stay float64 up to the
+    // float32 rounding of the matrices and of the DLT rows)
     float N1[9], N2[9], C1[9], C2[9], iC2[9], iN2[9];
-    std::vector<float> cf1((size_t)2 * n), cf2((size_t)2 * n);
-    rc = apap_host_prepare(src, dst, n, N1, N2, C1, C2, iC2, iN2, nullptr, nullptr, cf1.data(), cf2.data());
+    std::vector<double> cf1((size_t)2 * n), cf2((size_t)2 * n), src64((size_t)2 * n);
+    std::vector<float> aa((size_t)18 * n);
+    rc = apap_host_prepare_pts(src, src_f64, dst, dst_f64, n, N1, N2, C1, C2, iC2, iN2, nullptr, nullptr, cf1.data(), cf2.data());
     if (rc) return rc;
+    if ((rc = apap_host_dlt_rows_pts(cf1.data(), cf2.data(), n, src_f64 || dst_f64, aa.data()))) return rc;
+    for (size_t i = 0; i < (size_t)2 * n; ++i) src64[i] = src_f64 ? ((const double *)src)[i] : (double)((const float *)src)[i];
     std::vector<double> table((size_t)n * APAP_TABLE_STRIDE);
     double denorm[APAP_DENORM_DOUBLES];
-    if ((rc = apap_host_build_table(src, cf1.data(), cf2.data(), n, table.data()))) return rc;
+    if ((rc = apap_host_build_table_rows(src64.data(), aa.data(), n, table.data()))) return rc;
     if ((rc = apap_host_build_denorm(iC2, C1, iN2, N1, denorm))) return rc;
     const SyncOnExit drain;   // the async copies below read `table` and `denorm`
 

@@ -1116,7 +1116,7 @@ __device__ __forceinline__ void qr_resolve(const double *__restrict__ table, int
 // geometry the float32 estimate's anchors come from.  hinv_pad == nullptr: the solve writes H only.
 struct WarpEmit {
     double *hinv_pad;       // pair 0's tables (apap_warp_batch_device's workspace); pair k at + k * stride
-    float4 *frec, *fexact;
+    float4 *frec;
     long long hinv_stride, frec_stride;
     const double *mesh_w, *mesh_h;
     int n_w, n_h, mesh_rows, mesh_cols, final_w, final_h, off_x, off_y;
@@ -1761,10 +1761,7 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
 // the offsets only and is SHARED by all pairs of a batch,
 //   lut [final_h + final_w] i32 + 1 stamp word | fcol [final_w rounded up to 4] u32 | frow [final_h] uint2 | src_rows [2 rows + 2] i32
 // then, per pair of the batch, what depends on that pair's H grid,
-//   hinv_pad [cells][10] f64 | frec [(rows + 1)(cols + 1)][3] float4 | fexact [(rows + 1)(cols + 1)][3] float4
-// fexact (column-walk kernel): the cell's stored float32 inverse as it is - 9 floats, then 1.0f when they ARE the inverse the
-// exact path must use (a float32 grid's ordinary cell), 0 otherwise (a float64 grid, the extra row / column) - so that a
-// pixel in doubt is settled from registers instead of through a dependent load of hinv_pad.
+//   hinv_pad [cells][10] f64 | frec [(rows + 1)(cols + 1)][3] float4
 // frec, fcol, frow serve k_warp_fast: record of cell (r, c) at r (cols + 1) + c, row `rows` and column
 // `cols` hold the everything-in-doubt record; fcol[j] = cell column | (dx + 128) << 16, frow[i] = {cell row | stamp16 << 16,
 // float bits of dy}, dx / dy = signed distance from the cell's anchor (its middle pixel); pixels that are not
@@ -1773,7 +1770,6 @@ struct WarpWork {
     double *hinv_pad;   // pair 0; pair k at + k * hinv_stride doubles
     int *lut;
     float4 *frec;       // pair 0; pair k at + k * frec_stride float4
-    float4 *fexact;     // pair 0; same stride as frec
     unsigned *fcol;
     uint2 *frow;
     int *src_rows;      // [rows][2] source-row interval per cell row, then 1 flag word (bit 0: irregular mesh)
@@ -1804,19 +1800,17 @@ inline WarpWork warp_work_layout(void *base, int mesh_rows, int mesh_cols, int f
     const size_t frec_bytes = round256(((size_t)mesh_rows + 1) * ((size_t)mesh_cols + 1) * 3 * sizeof(float4));
     w.hinv_pad = (double *)p;
     w.frec = (float4 *)(p + hinv_bytes);
-    w.fexact = (float4 *)(p + hinv_bytes + frec_bytes);
-    w.hinv_stride = (long long)((hinv_bytes + 2 * frec_bytes) / sizeof(double));
-    w.frec_stride = (long long)((hinv_bytes + 2 * frec_bytes) / sizeof(float4));
-    p += (hinv_bytes + 2 * frec_bytes) * (size_t)(batch < 1 ? 1 : batch);
+    w.hinv_stride = (long long)((hinv_bytes + frec_bytes) / sizeof(double));
+    w.frec_stride = (long long)((hinv_bytes + frec_bytes) / sizeof(float4));
+    p += (hinv_bytes + frec_bytes) * (size_t)(batch < 1 ? 1 : batch);
     w.bytes = (size_t)(p - (char *)base);
     return w;
 }
 
 // entry `e` of the extra row / column of the record tables: everything in doubt, no exact floats
-__device__ __forceinline__ void warp_extra_entry(float4 *__restrict__ frec, float4 *__restrict__ fexact, size_t e) {
+__device__ __forceinline__ void warp_extra_entry(float4 *__restrict__ frec, size_t e) {
     const double z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     fast_record(z, false, 0.0, 0.0, 1.0, 1.0, frec + e * 3);
-    fexact[e * 3] = fexact[e * 3 + 1] = fexact[e * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // The warp's per-cell tables of mesh cell (er, ec) from its FORWARD matrix `m` (the grid's values, widened): the inverse in
@@ -1826,7 +1820,7 @@ template <typename T>
 __device__ __forceinline__ void warp_cell_tables(const double (&m)[9], int er, int ec, int mesh_cols, const double *__restrict__ mesh_w,
                                                  int n_w, const double *__restrict__ mesh_h, int n_h, int final_w, int final_h,
                                                  int off_x, int off_y, double *__restrict__ hinv_pad, T *__restrict__ hinv_dense,
-                                                 float4 *__restrict__ frec, float4 *__restrict__ fexact, int *status, int *src_rows,
+                                                 float4 *__restrict__ frec, int *status, int *src_rows,
                                                  const CellEdges *edges = nullptr) {
     const int cell = er * mesh_cols + ec;
     const size_t e = (size_t)er * (mesh_cols + 1) + ec;
@@ -1852,12 +1846,6 @@ __device__ __forceinline__ void warp_cell_tables(const double (&m)[9], int er, i
 #pragma unroll
         for (int k = 0; k < 9; ++k) hinv_dense[(size_t)cell * 9 + k] = (T)r[k];
     }
-    {   // the stored inverse itself, for the column-walk kernel's exact path (float32 grids: the floats ARE the inverse)
-        const float valid = sizeof(T) == sizeof(float) ? 1.0f : 0.0f;
-        fexact[e * 3] = make_float4((float)hd[0], (float)hd[1], (float)hd[2], (float)hd[3]);
-        fexact[e * 3 + 1] = make_float4((float)hd[4], (float)hd[5], (float)hd[6], (float)hd[7]);
-        fexact[e * 3 + 2] = make_float4((float)hd[8], valid, 0.f, 0.f);
-    }
     // anchor in the middle of the cell: the estimate's error grows with the distance from it
     fast_record(hd, okx && oky, (double)(x0 + sx / 2 - off_x), (double)(y0 + sy / 2 - off_y), (double)(sx - sx / 2),
                 (double)(sy - sy / 2), frec + e * 3, src_rows ? src_rows + 2 * er : nullptr);
@@ -1870,14 +1858,14 @@ __device__ void warp_emit_from_solve(const WarpEmit &we, int pair, int cell, con
     for (int k = 0; k < 9; ++k) m[k] = (double)Hf[k];
     const int er = cell / we.mesh_cols, ec = cell - er * we.mesh_cols;
     double *hinv_pad = we.hinv_pad + (long long)pair * we.hinv_stride;
-    float4 *frec = we.frec + (long long)pair * we.frec_stride, *fexact = we.fexact + (long long)pair * we.frec_stride;
+    float4 *frec = we.frec + (long long)pair * we.frec_stride;
     warp_cell_tables<float>(m, er, ec, we.mesh_cols, we.mesh_w, we.n_w, we.mesh_h, we.n_h, we.final_w, we.final_h, we.off_x, we.off_y,
-                            hinv_pad, (float *)nullptr, frec, fexact, we.status, (int *)nullptr, &edges);
+                            hinv_pad, (float *)nullptr, frec, we.status, (int *)nullptr, &edges);
     const size_t stride = (size_t)we.mesh_cols + 1;
-    if (ec == we.mesh_cols - 1) warp_extra_entry(frec, fexact, (size_t)er * stride + we.mesh_cols);
+    if (ec == we.mesh_cols - 1) warp_extra_entry(frec, (size_t)er * stride + we.mesh_cols);
     if (er == we.mesh_rows - 1) {
-        warp_extra_entry(frec, fexact, (size_t)we.mesh_rows * stride + ec);
-        if (ec == we.mesh_cols - 1) warp_extra_entry(frec, fexact, (size_t)we.mesh_rows * stride + we.mesh_cols);
+        warp_extra_entry(frec, (size_t)we.mesh_rows * stride + ec);
+        if (ec == we.mesh_cols - 1) warp_extra_entry(frec, (size_t)we.mesh_rows * stride + we.mesh_cols);
     }
 }
 
@@ -1891,7 +1879,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
                                                     int *__restrict__ lut, int *status, int off_x, int off_y,
                                                     float4 *__restrict__ frec, unsigned *__restrict__ fcol,
                                                     uint2 *__restrict__ frow, int *__restrict__ src_rows,
-                                                    long long hinv_stride, long long frec_stride, float4 *__restrict__ fexact) {
+                                                    long long hinv_stride, long long frec_stride) {
     // grid.y = pair of a batch (every pair has the same mesh and canvas: the lookup tables are built once, by
     // y = 0); blocks [0, inv_blocks) are the per-cell half - what depends on the H grid -, the rest the tables.
     // Either half may be absent from a launch (inv_blocks = 0, or a grid of inv_blocks blocks).
@@ -1909,13 +1897,12 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
         H += pair * (size_t)cells * 9;
         hinv_pad += pair * hinv_stride;
         frec += pair * frec_stride;
-        fexact += pair * frec_stride;
         if (hinv_dense) hinv_dense += pair * (size_t)cells * 9;
         const int e = blockIdx.x * 256 + tid;
         const int er = e / (mesh_cols + 1), ec = e - er * (mesh_cols + 1);
         if (er > mesh_rows) return;
         if (er == mesh_rows || ec == mesh_cols) {
-            warp_extra_entry(frec, fexact, e);
+            warp_extra_entry(frec, e);
             return;
         }
         const int cell = er * mesh_cols + ec;
@@ -1923,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
 #pragma unroll
         for (int k = 0; k < 9; ++k) m[k] = (double)H[(size_t)cell * 9 + k];
         warp_cell_tables<T>(m, er, ec, mesh_cols, mesh_w, n_w, mesh_h, n_h, final_w, final_h, off_x, off_y, hinv_pad, hinv_dense,
-                            frec, fexact, status, src_rows);
+                            frec, status, src_rows);
         return;
     }
     if (blockIdx.y != 0) return;
@@ -1985,9 +1972,13 @@ __global__ __launch_bounds__(256) void k_warp_setup(const T *__restrict__ H, int
     }
 }
 
-struct __attribute__((packed, aligned(4))) Bytes12 {
-    unsigned int a, b, c;
-};
+// 12 bytes to ANY byte address with the non-temporal hint (global_store_dwordx3 ... nt)
+__device__ __forceinline__ void store12_stream(uint8_t *p, unsigned a, unsigned b, unsigned c) {
+    typedef unsigned Dwords3 __attribute__((ext_vector_type(3)));
+    typedef Dwords3 Dwords3AnyByte __attribute__((aligned(1)));
+    const Dwords3 v = {a, b, c};
+    __builtin_nontemporal_store(v, reinterpret_cast<Dwords3AnyByte *>(p));
+}
 
 // target coordinate of canvas pixel (i, j) through the (already inverted) cell matrix:
 // float64 FMA chain in the order h0*x + h1*y + h2, then the two divisions by the third
@@ -2142,11 +2133,7 @@ __global__ __launch_bounds__(256) void k_warp(const uint8_t *__restrict__ img, i
     }
     uint8_t *o = out + (size_t)g * 3;
     if (g + 4u <= total) {
-        Bytes12 v;
-        v.a = px[0] | (px[1] << 24);
-        v.b = (px[1] >> 8) | (px[2] << 16);
-        v.c = (px[2] >> 16) | (px[3] << 8);
-        *reinterpret_cast<Bytes12 *>(o) = v;
+        store12_stream(o, px[0] | (px[1] << 24), (px[1] >> 8) | (px[2] << 16), (px[2] >> 16) | (px[3] << 8));
     } else {
         for (unsigned k = 0; k < 4u && g + k < total; ++k) {
             o[3 * k] = (uint8_t)(px[k] & 0xff);
@@ -2306,13 +2293,10 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
         }
         uint8_t *o = out + ((size_t)(y - row_begin) * (size_t)final_w) * 3 + (unsigned)j0 * 3u;
         if (npx == 4) {
-            Bytes12 v;
-            // 4 x 24 bits -> 3 dwords: one shift-or and two byte permutes (v_perm_b32 picks
-            // bytes 0-3 from its second operand, 4-7 from its first)
-            v.a = px[t][0] | (px[t][1] << 24);
-            v.b = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
-            v.c = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
-            __builtin_memcpy(o, &v, 12);  // rows start at any byte: an unaligned 12-byte store
+            // 4 x 24 bits -> 3 dwords: one shift-or and two byte permutes (v_perm_b32 picks bytes 0-3 from its second
+            // operand, 4-7 from its first); rows start at any byte: an unaligned, non-temporal 12-byte store
+            store12_stream(o, px[t][0] | (px[t][1] << 24), __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u),
+                           __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u));
         } else {
             for (int k = 0; k < npx; ++k) {
                 o[3 * k] = (uint8_t)(px[t][k] & 0xff);
@@ -2372,26 +2356,8 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
 #ifndef APAP_K3_WAVES_ATTR
 #define APAP_K3_WAVES_ATTR
 #endif
-#ifndef APAP_K3_PRIO
-#define APAP_K3_PRIO 0
-#endif
-#ifndef APAP_K3_LDSREC
-#define APAP_K3_LDSREC 0
-#endif
-#ifndef APAP_K3_XCD
-#define APAP_K3_XCD 0
-#endif
-#ifndef APAP_K3_A16
-#define APAP_K3_A16 0
-#endif
-#ifndef APAP_K3_NT
-#define APAP_K3_NT 1
-#endif
-#ifndef APAP_K3_BLOCK
-#define APAP_K3_BLOCK 256
-#endif
 template <bool kBlend, int kRows>
-__global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
+__global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
                                                    const double *__restrict__ hinv_pad, int mesh_rows, int mesh_cols,
                                                    const int *__restrict__ lut, const float4 *__restrict__ frec,
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
@@ -2410,42 +2376,11 @@ __global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef APAP_K3_TRACE
-    const unsigned k3_id = blockIdx.x * (blockDim.x >> 6) + (unsigned)wave;
+    const unsigned k3_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (unsigned)wave;
     APAP_K3_STAMP(0);
 #endif
-#if APAP_K3_PRIO
-    {
-        // the wave's slot on its SIMD (HW_REG_HW_ID bits 3:0) picks its issue priority
-        const unsigned slot = (unsigned)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
-        if (APAP_K3_PRIO >= 4) {        // stagger: some of a SIMD's waves start late
-            if (APAP_K3_PRIO == 4 && (slot & 1u)) __builtin_amdgcn_s_sleep(40);
-            if (APAP_K3_PRIO == 5 && (slot & 1u)) __builtin_amdgcn_s_sleep(80);
-            if (APAP_K3_PRIO == 6) {
-                if (slot & 1u) __builtin_amdgcn_s_sleep(16);
-                if (slot & 2u) __builtin_amdgcn_s_sleep(32);
-                if (slot & 4u) __builtin_amdgcn_s_sleep(64);
-            }
-        } else {
-        const unsigned p = APAP_K3_PRIO == 1 ? (slot & 3u) : APAP_K3_PRIO == 2 ? ((slot >> 1) & 3u) : (slot & 1u) * 3u;
-        if (p == 1u) __builtin_amdgcn_s_setprio(1);
-        else if (p == 2u) __builtin_amdgcn_s_setprio(2);
-        else if (p == 3u) __builtin_amdgcn_s_setprio(3);
-        }
-    }
-#endif
-    // tile of this workgroup: 256 canvas columns x (waves x kRows) rows.
-#if APAP_K3_XCD
-    // The launch is one-dimensional and workgroup L runs on XCD L % 8 (each XCD has its own L2): the column blocks of one
-    // strip-row - neighbours that share the cache lines at their common edges, in the canvas and in the source - all go
-    // to the XCD (L % 8), consecutive strip-rows to consecutive XCDs.  (A two-dimensional grid deals the 16 column blocks of a
-    // C3 strip-row over all eight L2s: every edge line written in two halves by two L2s.)
-    const int nbx = (final_w + 255) >> 8;
-    const int bid_x = (int)(blockIdx.x >> 3) % nbx, bid_y = ((int)(blockIdx.x >> 3) / nbx) * 8 + (int)(blockIdx.x & 7u);
-#else
-    const int bid_x = blockIdx.x, bid_y = blockIdx.y;
-#endif
-    const int j0 = (bid_x * 64 + lane) * 4;
-    const int y_first = row_begin + (bid_y * (int)(blockDim.x >> 6) + wave) * kRows;
+    const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
+    const int y_first = row_begin + ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * kRows;
     const int y_end = min(y_first + kRows, row_begin + row_count);
     if (j0 >= final_w || y_first >= y_end) return;
     const unsigned last = (unsigned)img_h * (unsigned)img_w * 3u - 4u;
@@ -2483,33 +2418,6 @@ __global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_
         col[k] = cev[k] & cmask;
         dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
-#if APAP_K3_LDSREC
-    // the cell records through LDS: a wave-row of 256 pixels meets a handful of cells, yet every lane used to fetch two
-    // 48-byte records per pass through the vector memory path (6 x 1 KiB of returned data per pass against 4 KiB of source
-    // pixels per strip), and only after its column entries had come back.  The wave's FIRST cell column comes from a scalar
-    // load of the column table instead, lanes 0-15 / 16-31 fetch the 16 records from there on of the strip's first / last
-    // cell row (in flight together with the lane's own column entries) and leave them in a wave-private LDS block; a pass
-    // reads its two records from there.  Strips that meet more than 16 cell columns or more than 2 cell rows (meshes finer
-    // than the strip), or whose cell columns do not ascend (irregular meshes), and the canvas's last, partly filled column
-    // block keep the direct loads.
-    __shared__ float4 s_rec[APAP_K3_BLOCK / 64][32][3];
-    const unsigned c_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(fcol[(unsigned)bid_x * 256u] & cmask));
-    {
-        const unsigned rsel = lane < 16 ? rr[0] : rr[kRows - 1];
-        const unsigned csel = min(c_lo + ((unsigned)lane & 15u), (unsigned)mesh_cols);
-        if (lane < 32) {
-            const float4 *pr = frec + (size_t)(rsel * (unsigned)(mesh_cols + 1) + csel) * 3;
-            const float4 r0 = pr[0], r1 = pr[1], r2 = pr[2];
-            s_rec[wave][lane][0] = r0;
-            s_rec[wave][lane][1] = r1;
-            s_rec[wave][lane][2] = r2;
-        }
-    }
-    bool rec_lds = bid_x * 256 + 128 <= final_w;      // lanes 0-31 are all alive (they fetched the records)
-#pragma unroll
-    for (int t = 1; t + 1 < kRows; ++t) rec_lds = rec_lds && (rr[t] == rr[0] || rr[t] == rr[kRows - 1]);
-    rec_lds = rec_lds && __builtin_amdgcn_ballot_w64((col[0] - c_lo > 15u) | (col[3] - c_lo > 15u)) == 0ull;
-#endif
     APAP_K3_STAMP(1);       // column and row entries have arrived
     unsigned off[kRows][4];
     unsigned int px[kRows][4];
@@ -2535,20 +2443,8 @@ __global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_
 #pragma unroll
         for (int t = 1; t < kRows; ++t) r = (t == first) ? rr[t] : r;
         const unsigned base = r * rec_stride;
-#if APAP_K3_LDSREC
-        float4 a0, a1, a2, b0, b1, b2;
-        if (rec_lds) {
-            const float4 *q = s_rec[wave][r == rr[0] ? 0 : 16];
-            const float4 *qa = q + (col[0] - c_lo) * 3u, *qb = q + (col[3] - c_lo) * 3u;
-            a0 = qa[0]; a1 = qa[1]; a2 = qa[2]; b0 = qb[0]; b1 = qb[1]; b2 = qb[2];
-        } else {
-            const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
-            a0 = pa[0]; a1 = pa[1]; a2 = pa[2]; b0 = pb[0]; b1 = pb[1]; b2 = pb[2];
-        }
-#else
         const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
         const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-#endif
         APAP_K3_STAMP(2);   // the records of this pass have arrived (the last pass's stamp stays)
         // per pixel: x-dependent parts of the three sums, the y coefficients, anchor, window
         float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
@@ -2665,17 +2561,6 @@ __global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_
 #endif
     APAP_K3_STAMP(4);       // exact path done (if taken), gathers issued AND landed
     const int y_store_end = ready ? y_end : y_first;     // a foreign workspace: no row is stored
-#if APAP_K3_A16
-    // A wave-row is 768 consecutive canvas bytes that start at ANY byte (a canvas row is 3 final_w bytes): sixty-four
-    // unaligned 12-byte stores per row.  Full wave-rows go through a wave-private LDS block instead - every lane leaves its
-    // 12 bytes there, lanes 0-47 take back one 16-byte piece each, cut at the 16-byte boundaries of the canvas ADDRESS (a
-    // wave-uniform byte shift: one v_alignbyte per dword), and store it aligned; the up to 15 bytes before the first and after the
-    // last boundary go out in one byte store (lanes 0-15 / 16-31).  The canvas's last, partly filled column block keeps the 12-byte stores.
-    __shared__ __attribute__((aligned(16))) unsigned s_row[APAP_K3_BLOCK / 64][kRows][196];
-    const bool full_row = bid_x * 256 + 256 <= final_w;
-#else
-    const bool full_row = false;
-#endif
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
         const int y = y_first + t;
@@ -2700,47 +2585,14 @@ __global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_
 #ifdef APAP_K3_ABL_NOSTORE
         if ((px[t][0] ^ px[t][1] ^ px[t][2] ^ px[t][3]) != 0x12345678u) continue;   // never true for 24-bit pixels
 #endif
-#if APAP_K3_A16
-        if (full_row) {
-            unsigned *mine = s_row[wave][t];
-            mine[3 * lane] = px[t][0] | (px[t][1] << 24);
-            mine[3 * lane + 1] = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
-            mine[3 * lane + 2] = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
-            uint8_t *row = out + ((size_t)(y - row_begin) * (size_t)final_w + (size_t)(bid_x * 256)) * 3;
-            const unsigned head = (unsigned)__builtin_amdgcn_readfirstlane((int)((0u - (unsigned)(uintptr_t)row) & 15u));
-            const unsigned pieces = (768u - head) >> 4, tail = (768u - head) & 15u;
-            if ((unsigned)lane < pieces) {
-                const unsigned *q = mine + (head >> 2) + 4u * (unsigned)lane;
-                const unsigned v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3], v4 = q[4], sh = head & 3u;
-                uint4 piece;
-                piece.x = __builtin_amdgcn_alignbyte(v1, v0, sh);
-                piece.y = __builtin_amdgcn_alignbyte(v2, v1, sh);
-                piece.z = __builtin_amdgcn_alignbyte(v3, v2, sh);
-                piece.w = __builtin_amdgcn_alignbyte(v4, v3, sh);
-                *reinterpret_cast<uint4 *>(row + head + 16u * (unsigned)lane) = piece;
-            }
-            const unsigned bi = lane < 16 ? (unsigned)lane : 768u - tail + (unsigned)(lane - 16);
-            const bool edge = lane < 16 ? (unsigned)lane < head : (unsigned)(lane - 16) < tail;
-            if (lane < 32 && edge) row[bi] = reinterpret_cast<const uint8_t *>(mine)[bi];
-            continue;
-        }
-#endif
         if (npx == 4) {
-#if APAP_K3_NT
-            // non-temporal: the canvas is written once and never read back here - the bytes stream past the L2 instead of
-            // waiting in it, dirty, for the write-back at the end of the kernel
-            typedef unsigned Dwords3 __attribute__((ext_vector_type(3)));
-            typedef Dwords3 Dwords3AnyByte __attribute__((aligned(1)));
-            const Dwords3 v = {px[t][0] | (px[t][1] << 24), __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u),
-                               __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u)};
-            __builtin_nontemporal_store(v, reinterpret_cast<Dwords3AnyByte *>(o));
-#else
-            Bytes12 v;
-            v.a = px[t][0] | (px[t][1] << 24);
-            v.b = __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u);
-            v.c = __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u);
-            __builtin_memcpy(o, &v, 12);
-#endif
+            // 4 x 24 bits -> 3 dwords (v_perm_b32 picks bytes 0-3 from its second operand, 4-7 from its first), stored
+            // NON-TEMPORAL: the canvas is written once and never read back by this kernel - the bytes stream past the L2
+            // instead of waiting in it, dirty, for the write-back at the end of the kernel (tools/k3_policy.hip: of the
+            // eight sc0 / sc1 / nt combinations on the stores and the eight on the gathers, nt stores + plain loads is the
+            // fastest; K3 at C3 16.0 -> 15.1 us warm, 19.3 -> 17.5 us cold)
+            store12_stream(o, px[t][0] | (px[t][1] << 24), __builtin_amdgcn_perm(px[t][2], px[t][1], 0x05040201u),
+                           __builtin_amdgcn_perm(px[t][3], px[t][2], 0x06050402u));
         } else {
             for (int k = 0; k < npx; ++k) {
                 o[3 * k] = (uint8_t)(px[t][k] & 0xff);
@@ -2750,305 +2602,6 @@ __global__ __launch_bounds__(256, kRows <= 4 ? 6 : 4) APAP_K3_WAVES_ATTR void k_
         }
     }
     APAP_K3_STAMP(5);       // stores issued and acknowledged
-}
-
-// K3, persistent column-walk form (round 4).  The strip kernel above gives every wave ONE strip and a chain of three
-// dependent memory round trips (column table -> cell records -> source pixels) before its stores; 9024 such waves on 6144
-// slots are 1.45 generations that compute together and then wait together (profiles/r03_k3_experiments.txt).  Here the grid
-// is sized to the chip (`waves_per_cu` resident waves on every CU, dynamic LDS caps the blocks per CU), the canvas
-// (all canvases of a batch) is cut into `wave-rows` - 256 pixels of one canvas row - in the order (pair, column block, row), and
-// every wave takes one CONTIGUOUS share of them: it walks DOWN a column block.  What that buys:
-//   * the column entries are loaded and unpacked once per wave, the cell records once per cell row the walk enters (every
-//     ~11 rows at C3) instead of once or twice per 4-row strip;
-//   * the walk is software-pipelined in stages of S rows: the gathers of stage i are in flight while stage i + 1's offsets are
-//     computed, and are waited for (counted vmcnt) only when stage i + 1's own gathers have been issued; the row entries of
-//     the next stage are prefetched by scalar loads;
-//   * no generations: every wave does the same amount of work (+- one wave-row), all start and end together.
-// Source pixels come through a buffer descriptor over the image: the hardware's range check returns 0 for the "outside"
-// marker 0xffffffff, so a gathered dword needs one AND instead of clamp / shift / sign mask; the image's very last pixel
-// (whose dword would reach one byte past the image) is taken out of the common path: it goes through the doubt loop and is
-// patched from a value read once per wave.  Per-pixel arithmetic, doubt rule and exact path are those of k_warp_fast.
-struct WalkGeo {
-    WarpStrides st;
-    int *status;
-    int img_h, img_w, mesh_rows, mesh_cols, final_w, final_h, off_x, off_y, center_h, center_w, row_begin, row_count;
-    unsigned nbx;        // column blocks of 256 pixels per canvas row
-    unsigned per, rem;   // wave-rows per wave: every wave takes `per`, the first `rem` waves one more
-};
-
-struct FastConst {      // per lane: what k_warp_fast keeps per pixel while it stays in one cell row
-    float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
-    int n0x[4], n0y[4];
-    unsigned thr[4];
-    float ea[10], eb[10];   // the stored inverses of the first and the last pixel's cells (fexact: 9 floats + valid flag)
-};
-
-__device__ __forceinline__ void load_fast_const(FastConst &c, const float4 *__restrict__ frec, const float4 *__restrict__ fexact,
-                                                unsigned base, const unsigned (&col)[4], const float (&dxf)[4]) {
-    const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
-    const float4 *xa = fexact + (size_t)(base + col[0]) * 3, *xb = fexact + (size_t)(base + col[3]) * 3;
-    const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-    {
-        const float4 u0 = xa[0], u1 = xa[1], u2 = xa[2], w0 = xb[0], w1 = xb[1], w2 = xb[2];
-        c.ea[0] = u0.x; c.ea[1] = u0.y; c.ea[2] = u0.z; c.ea[3] = u0.w; c.ea[4] = u1.x; c.ea[5] = u1.y; c.ea[6] = u1.z; c.ea[7] = u1.w;
-        c.ea[8] = u2.x; c.ea[9] = u2.y;
-        c.eb[0] = w0.x; c.eb[1] = w0.y; c.eb[2] = w0.z; c.eb[3] = w0.w; c.eb[4] = w1.x; c.eb[5] = w1.y; c.eb[6] = w1.z; c.eb[7] = w1.w;
-        c.eb[8] = w2.x; c.eb[9] = w2.y;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const bool is_a = (k == 0) || (k != 3 && col[k] == col[0]);
-        const float4 q0 = is_a ? a0 : b0, q1 = is_a ? a1 : b1, q2 = is_a ? a2 : b2;
-        c.nx0[k] = __builtin_fmaf(q0.x, dxf[k], q0.z);
-        c.ny0[k] = __builtin_fmaf(q0.w, dxf[k], q1.y);
-        c.dn0[k] = __builtin_fmaf(q1.w, dxf[k], q1.z);
-        c.bx[k] = q0.y; c.by[k] = q1.x; c.h7[k] = q2.x;
-        c.n0x[k] = __float_as_int(q2.y); c.n0y[k] = __float_as_int(q2.z);
-        c.thr[k] = __float_as_uint(q2.w);
-        // a third cell inside four pixels (cells narrower than the group): exact path
-        if (k == 1 || k == 2) c.thr[k] = (!is_a && col[k] != col[3]) ? 0xffffffffu : c.thr[k];
-    }
-}
-
-template <bool kBlend>
-__device__ __forceinline__ void walk_store_row(const WalkGeo &a, const uint8_t *__restrict__ center, uint8_t *__restrict__ out,
-                                               unsigned (&px)[4], int y, int j0, int npx, unsigned clast) {
-    if (kBlend) {
-        const int ci = y - a.off_y;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cj = j0 + k - a.off_x;
-            const bool in = ci >= 0 && ci < a.center_h && cj >= 0 && cj < a.center_w;
-            const unsigned co = in ? ((unsigned)ci * (unsigned)a.center_w + (unsigned)cj) * 3u : 0u;
-            const unsigned cc = co < clast ? co : clast;
-            unsigned int c;
-            __builtin_memcpy(&c, center + cc, 4);
-            c = in ? ((c >> (8 * (co - cc))) & 0x00ffffffu) : 0u;
-            const unsigned w = px[k];
-            const unsigned avg = (w & c) + (((w ^ c) & 0x00fefefeu) >> 1);
-            px[k] = (w != 0u && c != 0u) ? avg : (w | c);
-        }
-    }
-    uint8_t *o = out + ((size_t)(y - a.row_begin) * (size_t)a.final_w) * 3 + (unsigned)j0 * 3u;
-    if (npx == 4) {
-        Bytes12 v;
-        v.a = px[0] | (px[1] << 24);
-        v.b = __builtin_amdgcn_perm(px[2], px[1], 0x05040201u);
-        v.c = __builtin_amdgcn_perm(px[3], px[2], 0x06050402u);
-        __builtin_memcpy(o, &v, 12);
-    } else {
-        for (int k = 0; k < npx; ++k) {
-            o[3 * k] = (uint8_t)(px[k] & 0xff);
-            o[3 * k + 1] = (uint8_t)((px[k] >> 8) & 0xff);
-            o[3 * k + 2] = (uint8_t)((px[k] >> 16) & 0xff);
-        }
-    }
-}
-
-// One source pixel's dword through the image's buffer descriptor (a load hipcc counts: with ONE set of gathers carried around
-// the loop its own counted waits are right - it waits for the set where the set is used.  Two forms that were tried and dropped:
-// two sets in flight, where hipcc's wait counting across the back edge drains the queue early; and the gathers as inline asm with a
-// hand-placed s_waitcnt, which ran 2.5 x slower than this builtin with an identical instruction stream -
-// profiles/r04_k3_experiments.txt).
-__device__ __forceinline__ unsigned walk_gather(unsigned off, __amdgpu_buffer_rsrc_t rs) {
-    return (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0);
-}
-
-// the float32 estimate of one pixel (k_warp_fast's arithmetic): source byte offset or the "outside" marker, and whether the
-// pixel is in doubt (estimate within the cell's window of an integer, or the image's last pixel, which the buffer load must not
-// fetch)
-__device__ __forceinline__ unsigned walk_estimate(const FastConst &c, int k, float dy, int img_w, int img_h, unsigned last_off, bool &doubt) {
-    const float num_x = __builtin_fmaf(c.bx[k], dy, c.nx0[k]);
-    const float num_y = __builtin_fmaf(c.by[k], dy, c.ny0[k]);
-    const float den = __builtin_fmaf(c.h7[k], dy, c.dn0[k]);
-    const float rc = __builtin_amdgcn_rcpf(den);
-    const int fx = (int)(num_x * rc), fy = (int)(num_y * rc);      // 10.22 fixed point; NaN -> 0
-    const int ix = c.n0x[k] + (fx >> kFastFracBits), iy = c.n0y[k] + (fy >> kFastFracBits);
-    const unsigned lo = min((unsigned)fx << (32 - kFastFracBits), (unsigned)fy << (32 - kFastFracBits));
-    const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
-    const unsigned o = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
-    doubt = (lo < c.thr[k]) | (o == last_off);
-    return o;
-}
-
-// exact_offset() with the cell's inverse taken from registers (the float32 values ARE the stored inverse: fexact)
-__device__ __forceinline__ unsigned exact_offset_from(const float (&e)[9], int i, int j, int off_x, int off_y, int img_w, int img_h) {
-    Hinv9 h;
-    h.a = make_double2((double)e[0], (double)e[1]);
-    h.b = make_double2((double)e[2], (double)e[3]);
-    h.c = make_double2((double)e[4], (double)e[5]);
-    h.d = make_double2((double)e[6], (double)e[7]);
-    h.e = make_double2((double)e[8], 0.0);
-    double tx, ty;
-    target_from(h, (double)(j - off_x), (double)(i - off_y), tx, ty);
-    const int ix = (int)tx, iy = (int)ty;
-    const bool ok = (tx > 0.0) & (ty > 0.0) & (ix < img_w) & (iy < img_h);
-    return ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
-}
-
-template <bool kBlend, int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_warp_walk(const uint8_t *__restrict__ img_all, const double *__restrict__ hinv_all,
-                                                   const int *__restrict__ lut, const float4 *__restrict__ frec_all,
-                                                   const float4 *__restrict__ fexact_all,
-                                                   const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
-                                                   uint8_t *__restrict__ out_all, const uint8_t *__restrict__ center_all,
-                                                   const WalkGeo a) {
-    const int lane = threadIdx.x & 63;
-    const unsigned gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    unsigned u0 = gw * a.per + min(gw, a.rem);
-    const unsigned u1 = u0 + a.per + (gw < a.rem ? 1u : 0u);
-    if (u0 >= u1) return;
-    if (!warp_tables_ready(lut[a.final_w + a.final_h], a.mesh_rows, a.mesh_cols, a.final_w, a.final_h, a.status)) return;
-    const unsigned img_bytes = (unsigned)a.img_h * (unsigned)a.img_w * 3u;
-    const unsigned last_off = img_bytes - 3u;      // byte offset of the image's very last pixel
-    const unsigned clast = kBlend ? (unsigned)a.center_h * (unsigned)a.center_w * 3u - 4u : 0u;
-    const unsigned rec_stride = (unsigned)(a.mesh_cols + 1);
-    while (u0 < u1) {       // one pass per (pair, column block) the wave's share touches: usually one, sometimes two
-        const unsigned seg = u0 / (unsigned)a.row_count;
-        const unsigned yrel = u0 - seg * (unsigned)a.row_count;
-        const unsigned pair = seg / a.nbx, cb = seg - pair * a.nbx;
-        const unsigned n_rows = min((unsigned)a.row_count - yrel, u1 - u0);
-        u0 += n_rows;
-        const uint8_t *__restrict__ img = img_all + (long long)pair * a.st.img;
-        uint8_t *__restrict__ out = out_all + (long long)pair * a.st.out;
-        const uint8_t *__restrict__ center = kBlend ? center_all + (long long)pair * a.st.center : nullptr;
-        const double *__restrict__ hinv_pad = hinv_all + (long long)pair * a.st.hinv;
-        const float4 *__restrict__ frec = frec_all + (long long)pair * a.st.frec;
-        const float4 *__restrict__ fexact = fexact_all + (long long)pair * a.st.frec;
-        // the image as a buffer: offsets at or beyond img_bytes (the "outside" marker) read as 0
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), (short)0, (int)img_bytes, 0x00020000);
-        // the last pixel's three bytes: the dword one byte earlier, shifted (no byte beyond the image is touched)
-        unsigned last_px;
-        __builtin_memcpy(&last_px, img + (img_bytes - 4u), 4);
-        last_px >>= 8;
-        const int y_begin = a.row_begin + (int)yrel, y_end = y_begin + (int)n_rows;
-        const int j0 = ((int)cb * 64 + lane) * 4;
-        const bool active = j0 < a.final_w;
-        const int j0c = active ? j0 : ((a.final_w - 1) & ~3);        // idle lanes of the last block repeat its last group
-        const int npx = active ? min(4, a.final_w - j0) : 0;
-        const uint4 ce = *reinterpret_cast<const uint4 *>(fcol + j0c);
-        const unsigned cev[4] = {ce.x, ce.y, ce.z, ce.w};
-        unsigned col[4];
-        float dxf[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            col[k] = cev[k] & 0xffffu;
-            dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;
-        }
-        FastConst c;
-        unsigned cur = 0xfffffffeu;      // no cell row loaded yet
-        unsigned px[S][4];               // the gathered pixels of the stage in flight
-        unsigned patch = 0u;             // per lane: pixels of that stage that are the image's last pixel
-        int y_prev = -1;
-        int y = y_begin;
-        // row entries of the coming stage, prefetched (scalar loads)
-        uint2 en[S];
-#pragma unroll
-        for (int t = 0; t < S; ++t) en[t] = frow[(unsigned)min(y + t, y_end - 1)];
-        // A stage's gathers are in flight while the NEXT stage's row entries are fetched and its offsets computed; then they
-        // are waited for and stored, and the next stage's gathers go out into the same registers.
-        for (;;) {
-            unsigned off[S][4];
-            unsigned patch_new = 0u;
-            const int y_new = y < y_end ? y : -1;
-            if (y_new >= 0) {
-                unsigned rr[S];
-                float dyf[S];
-#pragma unroll
-                for (int t = 0; t < S; ++t) {
-                    rr[t] = __builtin_amdgcn_readfirstlane(en[t].x) & 0xffffu;       // (the upper half is the tables' stamp)
-                    dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(en[t].y));
-                }
-                y += S;
-                if (y < y_end) {
-#pragma unroll
-                    for (int t = 0; t < S; ++t) en[t] = frow[(unsigned)min(y + t, y_end - 1)];
-                }
-                unsigned long long doubt[S][4];     // lane masks (scalar registers)
-                unsigned long long any = 0;
-#pragma unroll
-                for (int t = 0; t < S; ++t) {
-                    if (rr[t] != cur) {     // the walk enters another cell row (wave-uniform)
-                        cur = rr[t];
-                        load_fast_const(c, frec, fexact, cur * rec_stride, col, dxf);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        bool d;
-                        off[t][k] = walk_estimate(c, k, dyf[t], a.img_w, a.img_h, last_off, d);
-                        doubt[t][k] = __builtin_amdgcn_ballot_w64(d);
-                        any |= doubt[t][k];
-                    }
-                }
-                if (any != 0) {
-                    // some pixel of the stage is in doubt (a few stages in a hundred on BASELINE's configurations; every stage
-                    // of a mesh the estimate has no bound for): the exact float64 sequence for those pixels.  The cell's stored
-                    // inverse is in registers (fexact) when the pixel sits in the first or the last pixel's cell of the cell
-                    // row whose constants are loaded - no dependent load, the wave does not fall behind the others; any
-                    // other pixel (a third cell inside the lane's four, an earlier cell row of this stage, a float64 grid,
-                    // a pixel outside every ordinary cell) takes the table path of k_warp_fast.
-                    unsigned bits = 0;
-#pragma unroll
-                    for (int t = 0; t < S; ++t)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) bits |= ((doubt[t][k] >> lane) & 1ull) ? (1u << (t * 4 + k)) : 0u;
-                    while (bits != 0u) {
-                        const int idx = __builtin_ctz(bits);
-                        bits &= bits - 1u;
-                        const int t = idx >> 2, k = idx & 3;
-                        const int i = min(y_new + t, y_end - 1), j = min(j0c + k, a.final_w - 1);
-                        unsigned cr = rr[0], cc = col[0];
-#pragma unroll
-                        for (int q = 1; q < S; ++q) cr = t == q ? rr[q] : cr;
-#pragma unroll
-                        for (int q = 1; q < 4; ++q) cc = k == q ? col[q] : cc;
-                        const bool in_a = cc == col[0], in_b = cc == col[3];
-                        const float valid = in_a ? c.ea[9] : c.eb[9];
-                        unsigned o;
-                        if (cr == cur && (in_a || in_b) && valid != 0.0f) {
-                            float e[9];
-#pragma unroll
-                            for (int q = 0; q < 9; ++q) e[q] = in_a ? c.ea[q] : c.eb[q];
-                            o = exact_offset_from(e, i, j, a.off_x, a.off_y, a.img_w, a.img_h);
-                        } else {
-                            o = exact_offset(hinv_pad, lut, a.mesh_rows, a.mesh_cols, a.final_h, cr, cc, i, j, a.off_x, a.off_y, a.img_w,
-                                             a.img_h);
-                        }
-                        if (o == last_off) {
-                            patch_new |= 1u << idx;
-                            o = 0xffffffffu;
-                        }
-#pragma unroll
-                        for (int tt = 0; tt < S; ++tt)
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) off[tt][kk] = (idx == tt * 4 + kk) ? o : off[tt][kk];
-                    }
-                }
-            }
-            if (y_prev >= 0) {
-                const bool patched = __builtin_amdgcn_ballot_w64(patch != 0u) != 0;
-#pragma unroll
-                for (int t = 0; t < S; ++t) {
-                    const int yy = y_prev + t;
-                    if (yy >= y_end) break;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) px[t][k] &= 0x00ffffffu;
-                    if (patched) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) px[t][k] = ((patch >> (t * 4 + k)) & 1u) ? last_px : px[t][k];
-                    }
-                    if (active) walk_store_row<kBlend>(a, center, out, px[t], yy, j0, npx, clast);
-                }
-            }
-            if (y_new < 0) break;
-#pragma unroll
-            for (int t = 0; t < S; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) px[t][k] = walk_gather(off[t][k], rs);
-            patch = patch_new;
-            y_prev = y_new;
-        }
-    }
 }
 
 // coordinates only (parity tests of the arithmetic of k_warp)
@@ -3202,11 +2755,7 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_FUSED_MAX_CELLS:
         case APAP_OPT_PLAN_CELLS: ok = value >= 0; break;
         case APAP_OPT_WARP_FAST:
-        case APAP_OPT_WARP_WALK:
         case APAP_OPT_OVERLAP_PCIE: ok = value == 0 || value == 1; break;
-        case APAP_OPT_WARP_WAVES: ok = value >= 4 && value <= 32 && value % 4 == 0; break;
-        case APAP_OPT_WARP_STAGE: ok = value == 1 || value == 2; break;
-        case APAP_OPT_WARP_MIN_RUN: ok = value >= 1; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
     }
     if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
@@ -3351,7 +2900,7 @@ int apap_solve_warp_batch_device(apap_ctx *ctx, const double *d_tables, int n, c
         return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_warp_batch_device: warp workspace %zu < %zu bytes", warp_work_bytes, need);
     const WarpWork ww = warp_work_layout(d_warp_work, mesh_rows, mesh_cols, final_w, final_h, batch);
     WarpEmit we;
-    we.hinv_pad = ww.hinv_pad; we.frec = ww.frec; we.fexact = ww.fexact;
+    we.hinv_pad = ww.hinv_pad; we.frec = ww.frec;
     we.hinv_stride = ww.hinv_stride; we.frec_stride = ww.frec_stride;
     we.mesh_w = d_mesh_w; we.mesh_h = d_mesh_h; we.n_w = n_w; we.n_h = n_h;
     we.mesh_rows = mesh_rows; we.mesh_cols = mesh_cols; we.final_w = final_w; we.final_h = final_h; we.off_x = off_x; we.off_y = off_y;
@@ -3448,7 +2997,7 @@ int warp_prologue(apap_ctx *ctx, const WarpArgs &a, WarpWork *ww, bool *fast_tab
                            ww->hinv_pad, Hinv_out, inv_blocks, a.mesh_w, a.n_w, a.mesh_h, a.n_h, a.mesh_rows, a.mesh_cols,
                            a.final_w, a.final_h, ww->lut, a.status, a.off_x, a.off_y, ww->frec, ww->fcol, ww->frow,
                            a.src_rows && geometry && per_cell && a.batch == 1 ? ww->src_rows : (int *)nullptr, ww->hinv_stride,
-                           ww->frec_stride, ww->fexact);
+                           ww->frec_stride);
     } else {
         if (per_cell) {
             ProfScope prof(ctx, APAP_PROF_INVERT, s);
@@ -3525,58 +3074,14 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
     // 254 pixels is one: meshes that coarse (on average) keep the all-float64 strip kernel.
     const bool fast_ok = strips && fast_tables && apap::opt(ctx, APAP_OPT_WARP_FAST) && final_w / mesh_cols <= 128 &&
                          final_h / mesh_rows <= 128;
-    const unsigned nbx = (unsigned)((final_w + 255) / 256);
-    const unsigned long long wave_rows = (unsigned long long)batch * nbx * (unsigned long long)row_count;
-    if (fast_ok && apap::opt(ctx, APAP_OPT_WARP_WALK) && wave_rows < (1ull << 31)) {
-        // persistent column-walk form: the grid is sized to the chip, every wave walks a contiguous share of the wave-rows
-        ProfScope prof(ctx, APAP_PROF_WARP, s);
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
-            cus = 256;
-        int wpc = apap::opt(ctx, APAP_OPT_WARP_WAVES);                 // resident waves per CU: 4-wave blocks, LDS-capped
-        const int bpc = wpc / 4 < 1 ? 1 : wpc / 4;
-        // small canvases: fewer waves, so that a wave still has a run of rows to pipeline
-        const unsigned long long min_rows = (unsigned long long)apap::opt(ctx, APAP_OPT_WARP_MIN_RUN);
-        unsigned long long blocks = (unsigned long long)cus * bpc;
-        if (wave_rows / min_rows < blocks * 4) blocks = (wave_rows / min_rows + 3) / 4;
-        if (blocks < 1) blocks = 1;
-        const unsigned waves = (unsigned)blocks * 4u;
-        WalkGeo w;
-        w.st = st;
-        w.status = a.status;
-        w.img_h = img_h; w.img_w = img_w; w.mesh_rows = mesh_rows; w.mesh_cols = mesh_cols; w.final_w = final_w; w.final_h = final_h;
-        w.off_x = off_x; w.off_y = off_y; w.center_h = center_h; w.center_w = center_w; w.row_begin = row_begin; w.row_count = row_count;
-        w.nbx = nbx;
-        w.per = (unsigned)(wave_rows / waves);
-        w.rem = (unsigned)(wave_rows % waves);
-        // dynamic LDS the kernel never touches: it caps the blocks a CU takes at `bpc`, so that the dispatcher spreads the
-        // grid evenly (160 KiB per CU; a block may ask for 64 KiB at most without an attribute)
-        size_t lds = (size_t)(160 * 1024) / (size_t)(bpc + 1) + 1024;
-        if (lds > 64 * 1024) lds = 64 * 1024;
-        const int stage = apap::opt(ctx, APAP_OPT_WARP_STAGE);
-#define APAP_LAUNCH_WALK(S_)                                                                                         \
-    if (d_center)                                                                                                    \
-        hipLaunchKernelGGL((k_warp_walk<true, S_>), dim3((unsigned)blocks), dim3(256), lds, s, d_img, hinv_pad, lut, ww.frec, ww.fexact, ww.fcol, \
-                           ww.frow, d_out, d_center, w);                                                             \
-    else                                                                                                             \
-        hipLaunchKernelGGL((k_warp_walk<false, S_>), dim3((unsigned)blocks), dim3(256), lds, s, d_img, hinv_pad, lut, ww.frec, ww.fexact, ww.fcol, \
-                           ww.frow, d_out, (const uint8_t *)nullptr, w)
-        if (stage >= 2) { APAP_LAUNCH_WALK(2); }
-        else { APAP_LAUNCH_WALK(1); }
-#undef APAP_LAUNCH_WALK
-    } else if (fast_ok) {
+    if (fast_ok) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;
 #ifndef APAP_K3_BLOCK
 #define APAP_K3_BLOCK 256
 #endif
         constexpr int kWpb = APAP_K3_BLOCK / 64;      // waves (= strips) per block
-#if APAP_K3_XCD
-        // one-dimensional: the kernel deals the tiles over the XCDs itself (strip-rows rounded up to a multiple of 8)
-        const dim3 grid((unsigned)((final_w + 255) / 256) * (unsigned)(((row_count + kWpb * rows - 1) / (kWpb * rows) + 7) / 8 * 8), 1, batch);
-#else
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + kWpb * rows - 1) / (kWpb * rows)), batch);
-#endif
 #define APAP_LAUNCH_FAST(R)                                                                                          \
     if (d_center)                                                                                                    \
         hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \

@@ -82,8 +82,8 @@ extern "C" {
  * float* where the context goes.  Such a caller must refuse to run: check apap_abi_version() ==
  * APAP_ABI_VERSION once after loading (cvx_proj_amd/_native.py does); a generation-1 library does not
  * export the symbol at all.  Bump on any change of an existing signature. */
-#define APAP_ABI_VERSION 4
-#define APAP_ABI_VERSION_STRING "0.4"
+#define APAP_ABI_VERSION 5
+#define APAP_ABI_VERSION_STRING "0.5"
 
 /* ---------------------------------------------------------------- diagnostics --- */
 const char *apap_last_error(void);
@@ -126,15 +126,7 @@ typedef struct apap_ctx apap_ctx;
                                       whatever the call holds - a shard of a mesh (cvx_proj_amd/dist.py) then sums every
                                       cell's keypoints in the order the whole mesh would on one GPU: the same bits for any
                                       number of ranks, at the price of fewer, larger blocks per GPU                      */
-#define APAP_OPT_WARP_WALK 11       /* K3 form: 0 = one strip of APAP_OPT_WARP_ROWS rows per wave; 1 = the persistent column-walk kernel:
-                                      a grid sized to the chip, every wave walks down a contiguous share of the canvas rows of one
-                                      256-pixel column block, software-pipelined (same canvas, byte for byte).  Default 0: measured
-                                      7-15 % slower than the strips on every BASELINE configuration (profiles/r04_k3_experiments.txt) */
-#define APAP_OPT_WARP_WAVES 12      /* tuning, column-walk form: resident waves per CU (a multiple of 4; default 16)              */
-#define APAP_OPT_WARP_STAGE 13      /* tuning, column-walk form: canvas rows per pipeline stage (1, 2; default 2)                   */
-#define APAP_OPT_WARP_MIN_RUN 14    /* tuning, column-walk form: small canvases get fewer waves so that a wave keeps at least this
-                                      many rows to pipeline (default 8)                                                            */
-#define APAP_OPT_COUNT 15
+#define APAP_OPT_COUNT 11
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);
@@ -159,6 +151,18 @@ int apap_host_prepare(const float *src, const float *dst, int n, float *N1, floa
 /* APAP.matrix_generate (apap.py:103-119): the 2n x 9 float32 DLT matrix. */
 int apap_host_dlt_rows(const float *cf1, const float *cf2, int n, float *aa);
 
+/* The same set-up in the dtype of the keypoints, as the reference's functions run when they are handed float64 points
+ * (nothing in apap.py:35-100 casts its argument: float64 keypoints stay float64 until the 3 x 3 matrices and the DLT rows
+ * are rounded into float32 arrays, apap.py:53-55,85-87,104-118).  src / dst: n x 2 float32 or float64, each with its own flag
+ * (numpy promotes per set).  nf*, cf* come back as float64 (a float32 set's values widened, exactly).  product_f64 of the
+ * DLT rows = "one of the two sets was float64": the products -cf2 * cf1 are then float64 products rounded once on the store;
+ * with both sets float32 the three *_pts functions give the bits of the float32 functions above. */
+int apap_host_prepare_pts(const void *src, int src_f64, const void *dst, int dst_f64, int n, float *N1, float *N2, float *C1,
+                          float *C2, float *iC2, float *iN2, double *nf1, double *nf2, double *cf1, double *cf2);
+int apap_host_dlt_rows_pts(const double *cf1, const double *cf2, int n, int product_f64, float *aa);
+/* the device point table from the DLT rows themselves (`aa`: 2n x 9 float32) and the float64 (or widened) source keypoints */
+int apap_host_build_table_rows(const double *src, const float *aa, int n, double *table);
+
 /* Device point table: per keypoint APAP_TABLE_STRIDE doubles -
  *   [0..29]  the 30 distinct entries of r1 r1^T + r2 r2^T, r1/r2 being the point's two
  *            float32 DLT rows (products of float32 values are exact in float64),
@@ -182,6 +186,12 @@ int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, 
 int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int n, const double *vertices,
                           int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
                           double *W_out, int device);
+/* The same for keypoints of either dtype (src_f64 / dst_f64: the array holds float64): the set-up then runs as the
+ * reference's does on such arrays (apap_host_prepare_pts), and the weights use the float64 source keypoints as they are
+ * (apap.py:150: `vertices - src_point` in float64).  apap_local_homography is this call with both flags 0. */
+int apap_local_homography_pts(apap_ctx *ctx, const void *src, int src_f64, const void *dst, int dst_f64, int n,
+                              const double *vertices, int mesh_rows, int mesh_cols, double gamma, double sigma, float *H_out,
+                              double *W_out, int device);
 
 /* The second return value of APAP.local_homography alone (apap.py:144,150-153,169): W_out[c][k] =
  * max(exp(-|vertices[c] - src[k]| / sigma^2), gamma), cells x n float64, for ANY list of `cells` sample points
@@ -189,6 +199,8 @@ int apap_local_homography(apap_ctx *ctx, const float *src, const float *dst, int
  * never reads this tensor (apap.py:242); computing it on demand keeps its 8 n bytes per cell off the default path. */
 int apap_local_weights(apap_ctx *ctx, const float *src, int n, const double *vertices, int cells, double gamma,
                        double sigma, double *W_out, int device);
+int apap_local_weights_pts(apap_ctx *ctx, const void *src, int src_f64, int n, const double *vertices, int cells, double gamma,
+                           double sigma, double *W_out, int device);
 
 /* APAP.local_warp (apap.py:186-217).
  *   img        img_h x img_w x 3 uint8

@@ -22,6 +22,8 @@ script is how they were made.
     C5          eight of the 64 independent pairs (pairs 0, 1 in full, 2..7 every 4th mesh row + SHA-256 of the grid)
     C5warp      c5_warp_k0 / c5_warp_k1: the reference's local_warp canvas of C5 pairs 0 and 1 (100 x 100 mesh over a 4K
                 canvas; SHA-256 + every 64th row) and the SHA-256 of the in-place inverses (~1 min each)
+    f64pts      f64pts_ref: keypoints that are not float32 arrays (float64, one float64 set beside a float32 one, int64)
+                through the reference as it is: every intermediate of the set-up and the H grids
     illcond     illcond_ref: the six soak seeds of round 1 whose weighted systems are numerically rank-deficient
                 (gamma = 0, sigma <= 10 px, 5-17 keypoints), through the reference's APAP.local_homography;
                 illcond_truth: five seeds of round 2's soak on which the reference's float64 SVD itself is lost,
@@ -341,6 +343,60 @@ def prepare_large_n(ref_apap, name="prepare_ref.npz"):
     print(f"{name}: set-up for n in {sizes}")
 
 
+def f64pts_cases(ref_apap, ref_utils, name="f64pts_ref.npz"):
+    """Keypoints that are NOT float32 arrays, through the reference as it is: float64 src and dst (a 5 x 5 case with every
+    intermediate; a C2-sized case: 500 keypoints, 100 x 100 mesh; 20001 keypoints - beyond numpy's 8192-element reduction
+    buffer - on a 6 x 6 mesh), one float64 set beside a float32 one (both ways round), and int64 keypoints."""
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)  # noqa: E731
+    out = {}
+
+    def one(tag, W, H, N, m, seed, kinds, sigma=100.0, gamma=0.5, keep_grid=1, intermediates=True):
+        rng = np.random.default_rng(seed)
+        Hg = np.array([[0.97, 0.04, -11.5 * W / 200], [-0.05, 1.03, -7.25 * H / 140], [1.5e-4 * 200 / W, -1e-4 * 200 / W, 1.0]])
+        src = rng.random((N, 2)) * [W, H]                                         # float64 values no float32 holds
+        q = np.concatenate([src, np.ones((N, 1))], axis=1) @ Hg.T
+        dst = q[:, :2] / q[:, 2:3] + 1.5 * W / 200 * np.sin(src * 9.6 / W) + rng.normal(0, 0.5, (N, 2))
+        if kinds[0] == "i8":
+            src, dst = np.rint(src).astype(np.int64), np.rint(dst).astype(np.int64)
+        else:
+            src, dst = src.astype(kinds[0]), dst.astype(kinds[1])
+        fw, fh, ox, oy = ref_utils.final_size(Shape((H, W, 3)), Shape((H, W, 3)), Hg)
+        vertices = ref_utils.get_vertice((fw, fh), m, (ox, oy))
+        eng = ref_apap.APAP(gamma, sigma, [fw, fh], [ox, oy])
+        d = dict(src=src, dst=dst, vertices=vertices, par=np.array([gamma, sigma]))
+        if intermediates:
+            N1, nf1 = eng.getNormalize2DPts(src)
+            N2, nf2 = eng.getNormalize2DPts(dst)
+            C1, C2 = eng.getConditionerFromPts(nf1), eng.getConditionerFromPts(nf2)
+            cf1, cf2 = eng.point_normalize(nf1, C1), eng.point_normalize(nf2, C2)
+            aa = eng.matrix_generate(N, cf1, cf2)
+            d.update(N1=N1, N2=N2, C1=C1, C2=C2)
+            if N <= 1000:
+                d.update(nf1=np.ascontiguousarray(nf1), nf2=np.ascontiguousarray(nf2), cf1=cf1, cf2=cf2, aa=aa)
+            else:
+                d.update(nf1_sha=sha(nf1), nf2_sha=sha(nf2), cf1_sha=sha(cf1), cf2_sha=sha(cf2), aa_sha=sha(aa))
+        H_ref, W_ref = eng.local_homography(src, dst, vertices)
+        d.update(H_sha=sha(H_ref), W00=W_ref[0, 0].copy(), Wlast=W_ref[-1, -1].copy())
+        d.update(H=H_ref[::keep_grid].copy(), H_rows_every=np.array(keep_grid))
+        # what the float32-narrowed keypoints would have given (the drop-in of rounds 1-4): how far the dtype matters
+        H32, _ = eng.local_homography(src.astype(np.float32), dst.astype(np.float32), vertices)
+        d.update(max_abs_diff_vs_float32_points=np.array(np.abs(H32.astype(np.float64) - H_ref).max()))
+        for k, v in d.items():
+            out[f"{tag}_{k}"] = v
+        print(f"  {tag}: n {N}, mesh {m}x{m}, dtypes {src.dtype}/{dst.dtype}, nf {nf1.dtype if intermediates else '-'}; "
+              f"max |H(f64 pts) - H(f32 pts)| = {float(d['max_abs_diff_vs_float32_points']):.3e}")
+
+    one("tiny", 200, 140, 120, 5, 71, ("f8", "f8"))
+    one("tiny6", 200, 140, 120, 5, 72, ("f8", "f8"), sigma=6.0)
+    one("mixa", 200, 140, 90, 4, 73, ("f8", "f4"))
+    one("mixb", 200, 140, 90, 4, 74, ("f4", "f8"))
+    one("ints", 200, 140, 60, 4, 75, ("i8", "i8"))
+    one("c2", 1920, 1080, 500, 100, 76, ("f8", "f8"), keep_grid=4)
+    one("big", 3840, 2160, 20001, 6, 77, ("f8", "f8"))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: {sorted(set(k.split('_')[0] for k in out))}")
+
+
 def keypoints_case(name="keypoints_ref.npz"):
     """The reference's keypoints.mat reader (utils.py:55-66, imported in place) on a synthetic
     file in the reference's directory layout: the file's four 6 x n matrices and what
@@ -415,6 +471,8 @@ def main():
     if "C4" in which:
         # ~7 minutes in the reference's Python loop; only every 8th mesh row is kept (720 KB)
         config_case(ref_apap, ref_utils, "C4", "c4_ref_rows8.npz", warp_rows_every=256, keep_rows_every=8)
+    if "f64pts" in which:
+        f64pts_cases(ref_apap, ref_utils)
     if "illcond" in which:
         illcond_cases(ref_apap)
         illcond_truth_cases(ref_apap)

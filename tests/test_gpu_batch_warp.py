@@ -256,7 +256,7 @@ def test_gather_on_an_unprepared_workspace_reports_and_touches_nothing(native):
     ref, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
     img = torch.from_numpy(p.img).to(dev)
     Hd = torch.from_numpy(H.reshape(-1, 9)).to(dev)
-    forms = [dict(), dict(warp_rows=2), dict(warp_rows=8), dict(warp_fast=0), dict(warp_rows=0), dict(warp_walk=1), dict(warp_walk=1, warp_stage=2)]
+    forms = [dict(), dict(warp_rows=2), dict(warp_rows=8), dict(warp_fast=0), dict(warp_rows=0)]
     for opts in forms:
         ctx = native.Context(**opts)
         try:

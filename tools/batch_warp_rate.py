@@ -26,10 +26,8 @@ def main():
     ap.add_argument("--batches", default="1,2,8,32")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--phases", type=int, default=N.WARP_ALL)
-    ap.add_argument("--walk", type=int, default=0)
-    ap.add_argument("--stage", type=int, default=2)
     a = ap.parse_args()
-    ctx = N.Context(warp_walk=a.walk, warp_stage=a.stage)
+    ctx = N.Context()
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
     for cfg in a.configs.split(","):
@@ -68,7 +66,7 @@ def main():
             assert int(st.cpu()[0]) == 0 and torch.equal(out[0], out[-1])
             base = base or us
             print(json.dumps({"config": cfg, "canvas": [p.final_w, p.final_h], "mesh": rows, "pairs_per_launch": b,
-                              "phases": a.phases, "walk": a.walk, "us_per_pair": round(us, 2), "mpix_per_s": round(p.final_w * p.final_h / us, 1),
+                              "phases": a.phases, "us_per_pair": round(us, 2), "mpix_per_s": round(p.final_w * p.final_h / us, 1),
                               "rate_vs_single_launch": round(base / us, 2)}), flush=True)
             del imgs, H, out, work
 

@@ -4,7 +4,7 @@ two ways - HIP events around every single launch (the context's profiling slots:
 launches back to back between two events (what rocprofv3's kernel duration + the ~1 us launch gap add up to) - warm
 (one image / canvas) and cold (a rotation of image / canvas sets larger than the Infinity Cache).
 
-    python tools/warp_forms.py [--config C3] [--steps 40] [--forms "strips;walk;walk,warp_stage=4;walk,warp_waves=8"]
+    python tools/warp_forms.py [--config C3] [--steps 40] [--forms "strips;strips,warp_rows=8;strips,warp_fast=0"]
 """
 import argparse
 import ctypes
@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--cold-mb", type=float, default=640.0)
-    ap.add_argument("--forms", default="strips;walk;walk,warp_stage=1;walk,warp_stage=4;walk,warp_waves=8;walk,warp_waves=12;walk,warp_waves=20")
+    ap.add_argument("--forms", default="strips;strips,warp_rows=2;strips,warp_rows=8;strips,warp_fast=0")
     ap.add_argument("--stitch", action="store_true")
     ap.add_argument("--condition-s", type=float, default=0.25)
     ap.add_argument("--rows", type=int, default=0, help="warp only the first N canvas rows (a band): how the time scales with the number of strips")
@@ -50,10 +50,8 @@ def main():
     for form in a.forms.split(";"):
         opts = {}
         for tok in form.split(","):
-            if tok == "walk":
-                opts["warp_walk"] = 1
-            elif tok == "strips":
-                opts["warp_walk"] = 0
+            if tok == "strips":
+                continue
             else:
                 k, v = tok.split("=")
                 opts[k] = int(v)
