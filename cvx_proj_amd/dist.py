@@ -305,9 +305,17 @@ class ShardedSolver:
         self._pending = []
         self._solve_kw = dict(self._kw)
         if solve_fn is hip_solve:                   # the engine's scratch: sized once for the larger launch
-            nb = max([max(_native.lib().apap_solve_workspace_bytes(_native._h(ctx), self.n, v.shape[0]), 256) if v.shape[0] else 256
+            lib = _native.lib()
+            nb = max([max(lib.apap_solve_workspace_bytes(_native._h(ctx), self.n, v.shape[0]),
+                          lib.apap_solve_batch_workspace_bytes(_native._h(ctx), self.n, v.shape[0], 1), 256) if v.shape[0] else 256
                       for v in self._vert])
             self._solve_kw["work"] = torch.empty(nb, dtype=torch.uint8, device=dev)
+        # the resident warp form (default engine, bands aligned to the rank's mesh rows): a WarpPlan over the rank's OWN mesh
+        # rows - canvas row / column tables built once, the per-cell half in the tail of the rank's solve -, so that a warp
+        # step is the gather kernel alone, as on one GPU (_make_plan)
+        self._plan = None
+        self._plan_tried = False
+        self._cells_ready = False
 
     def broadcast_inputs(self):
         """Keypoint table (n x 256 B) and de-normalisation block from rank 0 to every rank:
@@ -318,9 +326,61 @@ class ShardedSolver:
             d.broadcast(self.denorm, src=0)
         self._inputs_sent = True
 
+    def _band_geometry(self):
+        """Canvas rows per rank.  ALIGNED TO THE RANK'S OWN MESH ROWS when the row edges allow it: band r = the
+        canvas rows whose cell row rank r solved, so a rank warps from its own rows of the H grid - no wait for the all-gather -
+        and its per-cell set-up covers 1 / world of the cells.  The engine sees the rank's rows as a mesh of their own: edges
+        ``mesh_h[a : b + 1]`` with the last one opened to +inf on a multi-rank group (canvas rows outside the band must still
+        look up SOME cell; they are not warped).  Needs increasing row edges that start at or below 0 and reach the canvas's
+        last row (edges that stop short keep the unaligned bands: there the single-GPU path and the reference report an index
+        error for the uncovered rows, apap.py:207 - opening the last edge would silently warp them); any other mesh keeps
+        near-equal bands warped from the whole gathered grid."""
+        if hasattr(self, "bands"):
+            return
+        p = self.pair
+        edges = np.asarray(p.mesh[1], dtype=np.float64)
+        self._aligned = (len(edges) == self.rows + 1 and bool(np.all(np.diff(edges) > 0)) and edges[0] <= 0.0
+                         and bool(np.isfinite(edges).all()) and edges[-1] >= p.final_h)
+        if self._aligned:
+            first = lambda k: int(min(max(np.ceil(edges[k]), 0.0), p.final_h)) if k < self.rows else p.final_h   # noqa: E731
+            self.bands = [(first(ra), first(rb)) if rb > ra else (first(ra), first(ra)) for ra, rb in self.parts]
+            self.bands[0] = (0, self.bands[0][1])
+        else:
+            self.bands = row_partition(p.final_h, self.world)
+        self.max_band = max(b - a for a, b in self.bands)
+        ra, rb = self.my_rows
+        if self._aligned and rb > ra:
+            own = edges[ra:rb + 1].copy()
+            if self.world > 1:
+                own[-1] = np.inf
+            self._own_edges, self._warp_shape = own, (rb - ra, self.cols)
+        else:
+            self._own_edges, self._warp_shape = np.ascontiguousarray(edges), (self.rows, self.cols)
+
+    def _make_plan(self):
+        """The rank's WarpPlan (None when the injected compute functions, an unaligned mesh or an empty shard rule it out)."""
+        if self._plan_tried:
+            return self._plan
+        self._plan_tried = True
+        self._band_geometry()
+        ra, rb = self.my_rows
+        if self.solve_fn is hip_solve and self.warp_fn is hip_warp_rows and self._aligned and rb > ra and len(self.pair.mesh[0]) <= 4096 \
+                and len(self._own_edges) <= 4096:
+            p = self.pair
+            self._plan = WarpPlan((p.mesh[0], self._own_edges), self._warp_shape, p.final_w, p.final_h, p.off_x, p.off_y, self.dev,
+                                  ctx=self._ctx)
+        return self._plan
+
     def _solve_piece(self, k):
         """Launch piece k of this rank's rows into its (padded) shard buffer."""
         vert, mine = self._vert[k], self._mine[k]
+        plan = self._make_plan() if not self.overlap and self.solve_fn is hip_solve else None
+        if plan is not None and vert.shape[0] == plan.rows * plan.cols:
+            # the rank's rows in ONE launch whose tail leaves every cell warp ready in the plan's workspace
+            plan.solve(self.table, self.denorm, vert, self.pair.gamma, self.pair.sigma, out=mine, work=self._solve_kw.get("work"))
+            self._cells_ready = True
+            return mine
+        self._cells_ready = False
         kw = dict(self._solve_kw)
         if self.solve_fn is hip_solve:
             kw["out"] = mine
@@ -372,26 +432,9 @@ class ShardedSolver:
 
     def _warp_setup(self):
         """Once per pair: the source image reaches every rank by a broadcast from rank 0 (25 MB at 4K, 100 MB at 8K
-        - the transfer SURVEY.md 8e warns dominates a single warp).  Canvas rows are dealt in bands ALIGNED TO THE
-        RANK'S OWN MESH ROWS: band r = the canvas rows whose cell row rank r solved, so a rank warps
-        from its own rows of the H grid - no wait for the all-gather - and its set-up kernel inverts 1 / world of
-        the cells instead of all of them.  The engine sees the rank's rows as a mesh of their own: edges
-        ``mesh_h[a : b + 1]`` with the last one opened to +inf (canvas rows outside the band must still look up
-        SOME cell; they are not warped).  Needs increasing row edges starting at or below 0; any other mesh keeps
-        near-equal bands warped from the whole gathered grid."""
+        - the transfer SURVEY.md 8e warns dominates a single warp); bands, buffers and the rank's warp plan."""
         p, d = self.pair, self.dist
-        edges = np.asarray(p.mesh[1], dtype=np.float64)
-        # (edges that stop short of the canvas keep the unaligned bands: there the single-GPU path and the reference report an
-        # index error for the uncovered rows, apap.py:207 - opening the last edge to +inf would silently warp them)
-        self._aligned = (_collective(d, self.world) and len(edges) == self.rows + 1 and bool(np.all(np.diff(edges) > 0)) and edges[0] <= 0.0
-                         and bool(np.isfinite(edges).all()) and edges[-1] >= p.final_h)
-        if self._aligned:
-            first = lambda k: int(min(max(np.ceil(edges[k]), 0.0), p.final_h)) if k < self.rows else p.final_h   # noqa: E731
-            self.bands = [(first(ra), first(rb)) if rb > ra else (first(ra), first(ra)) for ra, rb in self.parts]
-            self.bands[0] = (0, self.bands[0][1])
-        else:
-            self.bands = row_partition(p.final_h, self.world)
-        self.max_band = max(b - a for a, b in self.bands)
+        self._band_geometry()
         if self.rank == 0 and p.img is not None:
             self.img = torch.from_numpy(np.ascontiguousarray(p.img)).to(self.dev)
         else:
@@ -399,18 +442,11 @@ class ShardedSolver:
         if _collective(d, self.world):
             d.broadcast(self.img, src=0)
         self.mesh_w = torch.from_numpy(np.ascontiguousarray(p.mesh[0])).to(self.dev)
-        ra, rb = self.my_rows
-        if self._aligned and rb > ra:
-            own = edges[ra:rb + 1].copy()
-            own[-1] = np.inf
-            self.mesh_h = torch.from_numpy(own).to(self.dev)
-            self._warp_shape = (rb - ra, self.cols)
-        else:
-            self.mesh_h = torch.from_numpy(np.ascontiguousarray(edges)).to(self.dev)
-            self._warp_shape = (self.rows, self.cols)
+        self.mesh_h = torch.from_numpy(self._own_edges).to(self.dev)
         if self.warp_fn is hip_warp_rows:       # the engine's scratch and status word: once
-            nb = _native.lib().apap_warp_workspace_bytes(self._warp_shape[0], self._warp_shape[1], p.final_w, p.final_h)
-            self._warp_kw = dict(self._kw, work=torch.empty(nb, dtype=torch.uint8, device=self.dev), status=self.status)
+            if self._make_plan() is None:       # (the plan carries its own)
+                nb = _native.lib().apap_warp_workspace_bytes(self._warp_shape[0], self._warp_shape[1], p.final_w, p.final_h)
+                self._warp_kw = dict(self._kw, work=torch.empty(nb, dtype=torch.uint8, device=self.dev), status=self.status)
         else:
             self._warp_kw = dict(self._kw)
         self._band = torch.zeros((max(self.max_band, 1), p.final_w, 3), dtype=torch.uint8, device=self.dev)
@@ -440,7 +476,16 @@ class ShardedSolver:
         else:
             self.finish()
             H = self.H
-        if b > a or single:
+        if (b > a or single) and self._plan is not None:
+            # resident form: the per-cell tables are in the plan's workspace (left there by the solve's tail, or built here
+            # from the rank's rows of the grid when the solve ran in two pieces) - the step is the gather kernel alone
+            if not self._cells_ready:
+                self._plan.cells(H)
+                self._cells_ready = True
+            target = self.out if single else self._band[:b - a]       # one rank: straight into the canvas
+            self._plan.gather(self.img, out=target.view(1, b - a, p.final_w, 3), rows=(a, b - a))
+            self.status = self._plan.status
+        elif b > a or single:
             st = self.warp_fn(self.img, H, self.mesh_w, self.mesh_h, p.final_w, p.final_h, p.off_x, p.off_y, a, b - a,
                               self.out if single else self._band, self._warp_shape, **self._warp_kw)   # one rank: straight into the canvas
             if st is not None:
@@ -500,14 +545,17 @@ def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
     return [out[k % world][k // world].cpu().numpy().reshape(rows, cols, 3, 3) for k in range(len(pairs))]
 
 
-def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=False, ctx=None):
+def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=False, ctx=None, plans=None):
     """The warp half of independent pairs (BASELINE config 5; the reference runs apap.py:186-217 once per pair): the
     pairs are dealt round-robin to the ranks like ``solve_pairs`` deals them, every rank warps ITS pairs in one batched
     set of launches (grid.z = pair), no collective on the data path.  ``grids[k]`` is pair k's H grid (rows, cols, 3, 3)
     - only the entries of this rank's pairs are read (None elsewhere is fine).  All pairs must share the image size, the
     mesh and the canvas geometry.  Returns ``{pair index: canvas (final_h, final_w, 3) uint8 tensor on dev}`` for this
     rank's pairs - 27 MB per 4K canvas: they stay where they were computed - or, with ``gather=True``, on rank 0 the
-    list of all canvases as numpy arrays in input order (``None`` on the other ranks): for tests and small batches."""
+    list of all canvases as numpy arrays in input order (``None`` on the other ranks): for tests and small batches.
+    ``plans``: a dict the CALLER keeps between calls - the rank's WarpPlan (workspace + the canvas row / column tables of this
+    geometry) is left in it, so that a later call on the same geometry and share of pairs skips the geometry phase and
+    allocates nothing (default engine only)."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     mine = list(range(rank, len(pairs), world))
@@ -524,7 +572,15 @@ def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=Fals
         mesh_w = torch.from_numpy(np.ascontiguousarray(p0.mesh[0], dtype=np.float64)).to(dev)
         mesh_h = torch.from_numpy(np.ascontiguousarray(p0.mesh[1], dtype=np.float64)).to(dev)
         kw = {"ctx": ctx} if ctx is not None else {}
-        out, status = warp_fn(imgs, H, mesh_w, mesh_h, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols), **kw)
+        if plans is not None and warp_fn is hip_warp_batch and len(p0.mesh[0]) <= 4096 and len(p0.mesh[1]) <= 4096:
+            key = (rows, cols, p0.final_w, p0.final_h, p0.off_x, p0.off_y, len(mine), str(dev), p0.mesh.tobytes())
+            plan = plans.get(key)
+            if plan is None:
+                plan = plans[key] = WarpPlan(p0.mesh, (rows, cols), p0.final_w, p0.final_h, p0.off_x, p0.off_y, dev, batch=len(mine), ctx=ctx)
+            plan.cells(H.view(-1, 9))
+            out, status = plan.gather(imgs), plan.status
+        else:
+            out, status = warp_fn(imgs, H, mesh_w, mesh_h, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols), **kw)
         if status is not None and int(status.cpu()[0]) != 0:
             word = int(status.cpu()[0])
             code = _native.ERR_SINGULAR if word & 1 else _native.ERR_INDEX if word & 2 else _native.ERR_INVALID_ARG

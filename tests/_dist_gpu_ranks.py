@@ -47,6 +47,14 @@ def main():
     assert s._aligned                                     # bands = the canvas rows of the mesh rows this rank solved
     H_step, band_step = s.step()                          # solve -> H gather in flight -> warp of the own band -> wait
     assert np.array_equal(H_step.cpu().numpy(), H) and np.array_equal(band_step.cpu().numpy(), canvas[lo:hi])
+    # the resident warp form: one launch per rank whose tail leaves the rank's cells warp ready in its WarpPlan, the warp step
+    # is then the gather kernel alone on the rank's band (no set-up launch) - same grid, same bytes
+    assert s_one._plan is not None and s_one._cells_ready and s._plan is not None
+    H_one, band_one = s_one.step()
+    assert s_one._cells_ready
+    assert np.array_equal(H_one.cpu().numpy(), H) and np.array_equal(band_one.cpu().numpy(), canvas[lo:hi])
+    assert np.array_equal(s_one.warp().cpu().numpy(), canvas) and np.array_equal(s_one.warp(gather=False).cpu().numpy(), canvas[lo:hi])
+    assert int(s_one.status.cpu()[0]) == 0
     pairs = [config_pair("C1", with_image=False, seed_offset=k) for k in range(5)]
     grids = solve_pairs(pairs, dev, dist)
     gathered = [None] * world

@@ -57,6 +57,14 @@ def test_c5_batched_warp_vs_reference(native, golden):
             assert sha(c) == g["warped_sha256"].tobytes()
             assert sha(hinv) == g["Hinv_sha256"].tobytes()
     assert not np.array_equal(canv[0].cpu().numpy(), canv[1].cpu().numpy())
+    # a caller that keeps the plan dict: the second call finds the workspace and the geometry tables of the first
+    plans = {}
+    again = warp_pairs(pairs, grids, dev, plans=plans)
+    (plan,) = plans.values()
+    again2 = warp_pairs(pairs[::-1], grids[::-1], dev, plans=plans)
+    assert list(plans.values()) == [plan] and int(plan.status.cpu()[0]) == 0
+    for k in range(4):
+        assert torch.equal(again[k], canv[k]) and torch.equal(again2[3 - k], canv[k])
     # the inverses the batch entry point writes back (what the reference leaves in its argument), all pairs at once
     H = torch.stack([torch.from_numpy(g.reshape(-1, 9)) for g in grids]).to(dev)
     imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)

@@ -108,3 +108,42 @@ def test_bench_with_a_one_rank_rccl_group():
     phases = [json.loads(ln)["bench_phase"] for ln in r.stderr.splitlines() if ln.startswith('{"bench_phase"')]
     assert phases[:2] == ["process group up", "first collective done"] and any(p.startswith("cells") for p in phases)
     assert all(json.loads(ln)["backend"] == "nccl" for ln in r.stderr.splitlines() if ln.startswith('{"bench_phase"'))
+
+
+def test_single_process_sharded_solver_keeps_a_warp_plan(native):
+    """No process group at all (what ``bench.py`` runs as `cells` on one GPU): the solver holds a WarpPlan over the whole mesh,
+    the solve's tail leaves the cells warp ready, ``warp()`` / ``step()`` launch the gather kernel alone - and the canvas is the
+    single-call one byte for byte."""
+    import torch
+    from cvx_proj_amd.dist import ShardedSolver
+    dev = torch.device("cuda", 0)
+    p = config_pair("C2")
+    s = ShardedSolver(p, dev)
+    H = s.solve().cpu().numpy().reshape(100, 100, 3, 3)
+    assert s._plan is not None and s._cells_ready and s._aligned and s.bands == [(0, p.final_h)]
+    ctx = native.Context(profile=1)
+    try:
+        s2 = ShardedSolver(p, dev, ctx=ctx)
+        s2.solve()
+        s2.warp()
+        ctx.profile_read()
+        for _ in range(3):
+            s2.warp()
+        prof = ctx.profile_read()
+        assert prof["warp"][1] == 3 and prof.get("invert", (0, 0))[1] == 0, prof       # three gathers, no set-up launch
+        H2, canvas2 = s2.step()
+        assert np.array_equal(H2.cpu().numpy().reshape(H.shape), H)
+    finally:
+        ctx.close()
+    want, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+    assert np.array_equal(s.warp().cpu().numpy(), want) and np.array_equal(canvas2.cpu().numpy(), want)
+    assert int(s.status.cpu()[0]) == 0
+    # a mesh whose row edges stop short of the canvas keeps the all-phase call and reports the reference's IndexError rows
+    import copy
+    q = copy.copy(p)
+    q.mesh = p.mesh.copy()
+    q.mesh[1] = p.mesh[1] * 0.5
+    s3 = ShardedSolver(q, dev)
+    s3.solve()
+    s3.warp()
+    assert s3._plan is None and not s3._aligned and int(s3.status.cpu()[0]) & 2

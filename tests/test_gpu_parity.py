@@ -72,6 +72,31 @@ def test_config_grid_vs_reference(native, golden, variant, cfg, name):
     assert np.array_equal(H, g["H_ref"]), f"{int((H != g['H_ref']).sum())} float32 values differ from the reference's grid"
 
 
+@pytest.mark.parametrize("tag", ["tiny", "tiny6", "mixa", "mixb", "ints", "c2", "big"])
+def test_keypoints_that_are_not_float32_vs_reference(native, golden, tag):
+    """VERDICT r4 item 3.  float64 keypoints (two float64 sets, one beside a float32 one either way round, int64 points,
+    a C2-sized case, 20 001 keypoints) through the reference as it is (make_golden.py f64pts): the drop-in no longer narrows
+    them - every float32 value of the grid equals the reference's, and the weights use the float64 source keypoints."""
+    import hashlib
+    g = golden("f64pts_ref")
+    src, dst, vertices = g[f"{tag}_src"], g[f"{tag}_dst"], g[f"{tag}_vertices"]
+    gamma, sigma = (float(v) for v in g[f"{tag}_par"])
+    H, W = native.local_homography(src, dst, vertices, gamma, sigma, want_weights=True)
+    every = int(g[f"{tag}_H_rows_every"])
+    assert np.array_equal(H[::every], g[f"{tag}_H"]), f"{int((H[::every] != g[f'{tag}_H']).sum())} float32 values differ"
+    assert np.array_equal(np.frombuffer(hashlib.sha256(H.tobytes()).digest(), dtype=np.uint8), g[f"{tag}_H_sha"])
+    assert np.allclose(W[0, 0], g[f"{tag}_W00"], rtol=8e-15, atol=0) and np.allclose(W[-1, -1], g[f"{tag}_Wlast"], rtol=8e-15, atol=0)
+    # ... and through the mirror class, whose lazy weights keep the keypoints' dtype too
+    fw = fh = 16
+    eng = APAP(gamma, sigma, [fw, fh], [0, 0])
+    H2, W2 = eng.local_homography(src, dst, vertices)
+    assert np.array_equal(H2, H)
+    assert np.allclose(np.asarray(W2[0, 0]), g[f"{tag}_W00"], rtol=8e-15, atol=0)
+    # narrowed to float32 the same keypoints give another grid (what rounds 1-4 returned)
+    H32, _ = native.local_homography(src.astype(np.float32), dst.astype(np.float32), vertices, gamma, sigma, want_weights=False)
+    assert not np.array_equal(H32, H)
+
+
 def test_weights_checksum_c2(native, golden):
     g = golden("c2_ref")
     p = config_pair("C2", with_image=False)

@@ -129,3 +129,31 @@ def test_config_reader(tmp_path):
     f.write_text("em_steps = 2\naffinity_eps = 30.0\nmesh_size = 40\nsigma = 12.5  # comment\n")
     cfg = read_config(str(f))
     assert cfg["mesh_size"] == "40" and float(cfg["sigma"]) == 12.5 and cfg["em_steps"] == "2"
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny6", "mixa", "mixb", "ints", "c2", "big"])
+def test_c_prepare_in_the_dtype_of_the_keypoints(native, golden, tag):
+    """float64 keypoints are NOT narrowed - the C set-up runs in the dtype of each point set, as the
+    reference's functions do (apap.py:35-100), and reproduces the reference's matrices, normalised points and DLT rows bit
+    for bit (float64 sets, one float64 set beside a float32 one, int64 keypoints, 20 001 keypoints)."""
+    import hashlib
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)  # noqa: E731
+    g = golden("f64pts_ref")
+    src, dst = g[f"{tag}_src"], g[f"{tag}_dst"]
+    q = native.host_prepare(src, dst)
+    aa = native.host_dlt_rows(q["cf1"], q["cf2"])
+    for k in ("N1", "N2", "C1", "C2"):
+        assert np.array_equal(q[k], g[f"{tag}_{k}"]), k
+    assert np.array_equal(q["iC2"], np.linalg.inv(g[f"{tag}_C2"])) and np.array_equal(q["iN2"], np.linalg.inv(g[f"{tag}_N2"]))
+    for k, v in (("nf1", q["nf1"]), ("nf2", q["nf2"]), ("cf1", q["cf1"]), ("cf2", q["cf2"]), ("aa", aa)):
+        if f"{tag}_{k}" in g:
+            assert v.dtype == g[f"{tag}_{k}"].dtype and np.array_equal(v, g[f"{tag}_{k}"]), k
+        else:
+            assert np.array_equal(sha(v), g[f"{tag}_{k}_sha"]), k
+    # the device table: moments of the DLT rows + the source keypoints as float64, untouched
+    table = native.host_build_table(src, q["cf1"], q["cf2"])
+    assert np.array_equal(table[:, 30:32], np.asarray(src, np.float64))
+    r = aa.astype(np.float64).reshape(-1, 2, 9)
+    m = np.einsum("kri,krj->kij", r, r)
+    want = np.stack([m[:, i, j] for i, j in MOMENT_INDEX], axis=1)
+    assert np.array_equal(table[:, :30], want)

@@ -194,3 +194,37 @@ def test_flatten_layout():
     inv /= inv[2, 2]
     assert np.allclose(out[5].reshape(3, 3).T, inv, rtol=1e-5)
     assert out[5][8] == 1.0
+
+
+F64_TAGS = ["tiny", "tiny6", "mixa", "mixb", "ints", "c2", "big"]
+
+
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("tag", F64_TAGS)
+def test_keypoints_that_are_not_float32_prepare(golden, tag):
+    """float64 keypoints (and one float64 set beside a float32 one, and int64 ones) through the reference's own
+    set-up functions (make_golden.py f64pts): the oracle gives every intermediate in the reference's dtype, bit for bit."""
+    g = golden("f64pts_ref")
+    p = O.prepare(g[f"{tag}_src"], g[f"{tag}_dst"])
+    for k in ("N1", "N2", "C1", "C2"):
+        assert np.array_equal(p[k], g[f"{tag}_{k}"]) and p[k].dtype == np.float32, k
+    for k in ("nf1", "nf2", "cf1", "cf2", "aa"):
+        if f"{tag}_{k}" in g:
+            assert p[k].dtype == g[f"{tag}_{k}"].dtype and np.array_equal(p[k], g[f"{tag}_{k}"]), k
+        else:
+            assert np.array_equal(_sha(p[k]), g[f"{tag}_{k}_sha"]), k
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny6", "mixa", "mixb", "ints"])
+def test_keypoints_that_are_not_float32_loop(golden, tag):
+    g = golden("f64pts_ref")
+    gamma, sigma = (float(v) for v in g[f"{tag}_par"])
+    H, W = O.local_homography_loop(g[f"{tag}_src"], g[f"{tag}_dst"], g[f"{tag}_vertices"], gamma, sigma)
+    assert np.array_equal(H, g[f"{tag}_H"])
+    assert np.array_equal(W[0, 0], g[f"{tag}_W00"]) and np.array_equal(W[-1, -1], g[f"{tag}_Wlast"])
+    # the dtype matters: the same keypoints narrowed to float32 give another grid
+    assert float(g[f"{tag}_max_abs_diff_vs_float32_points"]) > 0
