@@ -587,6 +587,33 @@ def selftest(rank, world):
 
 
 # --------------------------------------------------------------------------------------------- main
+def roofline_k2(config, res, kern, kern_plain, tj, fused):
+    """K2 (k_eigen_denorm) against HBM: counter bytes per launch (profiles/pmc_traffic.json: 2 x FETCH_SIZE - its reads are
+    16 bytes per lane, the case the guide's correction doubles - + WRITE_SIZE) and the bytes the algorithm needs, over the
+    kernel's own duration, for the stand-alone solve's K2 and for the resident step's (whose tail also writes every cell's
+    inverse and float32-estimate record for the warp)."""
+    if fused or not kern.get("eigen"):
+        return None
+    cells = res.cells * res.batch
+    splits = N.lib().apap_solve_workspace_bytes(res.ctx, res.n, res.cells) // (30 * 8 * ((res.cells + 63) // 64 * 64))
+    # reads: the moment slabs (30 doubles per cell and keypoint split) + 2 vertices doubles; writes: 9 floats
+    algo_plain = cells * (splits * 240 + 16 + 36)
+    # the tail: + 2 x 2 edge doubles read, + 10 doubles of padded inverse and a 48-byte record written
+    algo_ready = algo_plain + cells * (32 + 80 + 48)
+    out = {"kernel": "k_eigen_denorm", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "keypoint_splits": int(splits),
+           "note": "one wave per SIMD walking a ~900-instruction dependent chain per cell: bound by that chain, not by bytes - the "
+                   "fraction says how little of the HBM a launch of 625 waves can ask for.  A single slab (no keypoint splits: K2 reads "
+                   "half) was measured: K2 -0.7 us, K1 +32 us (625 blocks on 256 CUs), profiles/r05_summary.txt"}
+    for tag, ms, algo in (("plain", kern_plain.get("eigen"), algo_plain), ("warp_ready", kern.get("eigen"), algo_ready)):
+        if not ms:
+            continue
+        counter = tj.get(f"{config}:k_eigen_denorm:{tag}")
+        out[tag] = {"kernel_ms": ms, "timing": "a pair of HIP events per launch (+ ~2 us of event handling)",
+                    "algorithmic_bytes": int(algo), "achieved": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                    "traffic": counter, "traffic_gbs": None if counter is None else counter / (ms * 1e-3) / 1e9}
+    return out
+
+
 def read_kernel_ms(ctx):
     """Average milliseconds per launch of every kernel slot the context bracketed since the last read."""
     prof = ctx.profile_read()
@@ -816,6 +843,10 @@ def main():
         res.warp_standalone(stream)
     torch.cuda.synchronize()
     kern["invert"] = read_kernel_ms(ctx)["invert"]
+    for _ in range(a.steps):            # K2 without the warp-ready tail (the stand-alone solve)
+        res.solve_plain(stream)
+    torch.cuda.synchronize()
+    kern_plain = read_kernel_ms(ctx)
     res.solve(stream)
     kern_cold = None
     if cold:
@@ -1130,6 +1161,7 @@ def main():
                                  "accumulation FMAs AND the ~20-instruction fp64 weight chain per (cell, keypoint), which "
                                  "the algorithmic count prices at 58 flops; the kernel runs ~266 issue cycles per 64 "
                                  "pairs whatever the MFMA shape (profiles/r02_k1_variants.txt, DESIGN.md section 3)"},
+            "roofline_k2": roofline_k2(a.config, res, kern, kern_plain, tj, fused),
             "roofline_warp": {
                 "kernel": k3_name, "cache": "warm", "bound": "hbm", "achieved": warp_bytes / (k3_warm_ms * 1e-3) / 1e9,
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (k3_warm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
