@@ -106,3 +106,33 @@ def test_page_locked_passes_in_a_row_do_not_share_results(native):
         pipe.run_pair(np.zeros_like(p.src), np.zeros_like(p.dst), p.Hg, p.shape, p.shape, 20, p.gamma, p.sigma, other_img=img_pin)
     flat, canvas = pipe.run_pair(p.src, p.dst, p.Hg, p.shape, p.shape, 20, p.gamma, p.sigma, other_img=img_pin)
     assert np.array_equal(flat, kept[0][1])     # and the pipeline works on afterwards
+
+
+def test_float64_keypoints_through_every_resident_path(native):
+    """Keypoints that are float64 arrays (values no float32 holds) give, through the resident pass, the chain of calls, the
+    sharded solver and the pair dealer, the grid of the host-buffer call - which `test_keypoints_that_are_not_float32_vs_reference`
+    pins to the reference - and not the grid of the same keypoints narrowed to float32."""
+    import copy
+    import torch
+    from cvx_proj_amd import apap as A
+    from cvx_proj_amd.dist import ShardedSolver, solve_pairs
+    from cvx_proj_amd.pipeline import Pipeline
+    p = config_pair("C1")
+    rng = np.random.default_rng(11)
+    q = copy.copy(p)
+    q.src = p.src.astype(np.float64) + rng.uniform(-1e-4, 1e-4, p.src.shape)
+    q.dst = p.dst.astype(np.float64) + rng.uniform(-1e-4, 1e-4, p.dst.shape)
+    m = p.vertices.shape[0]
+    H, _ = native.local_homography(q.src, q.dst, q.vertices, q.gamma, q.sigma, want_weights=False)
+    H32, _ = native.local_homography(q.src.astype(np.float32), q.dst.astype(np.float32), q.vertices, q.gamma, q.sigma, want_weights=False)
+    assert not np.array_equal(H, H32)
+    flat, canvas, grid = Pipeline().run_pair(q.src, q.dst, q.Hg, q.shape, q.shape, m, q.gamma, q.sigma, other_img=q.img, want_grid=True)
+    assert np.array_equal(grid, H)
+    flat2, canvas2 = A.run_pair_by_calls(q.src, q.dst, q.Hg, q.shape, q.shape, m, q.gamma, q.sigma, other_img=q.img)
+    assert np.array_equal(flat, flat2) and np.array_equal(canvas, canvas2)
+    dev = torch.device("cuda", 0)
+    s = ShardedSolver(q, dev, same_bits=True)
+    assert np.array_equal(s.solve().cpu().numpy().reshape(H.shape), H)
+    assert np.array_equal(s.warp().cpu().numpy(), canvas)
+    grids = solve_pairs([q, p], dev)
+    assert np.array_equal(grids[0], H) and not np.array_equal(grids[1], H)
