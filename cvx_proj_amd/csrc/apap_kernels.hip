@@ -1660,17 +1660,20 @@ constexpr int kMaxEdges = 4096;  // per axis; larger meshes take the linear-scan
 // R = t0b - Q t2b a rounding residual.  The kernel evaluates, in float32 with exactly two FMAs per
 // sum, one v_rcp_f32 and one multiply,
 //     s = (c' + a' dx + b' dy) / (t2b + h6 dx + h7 dy),   a' = A + f h6, b' = B + f h7, c' = f t2b,
-// with f = f0 + dE: the estimate of tx - n0 shifted up by dE, everything scaled by 2^22 so that
-// int(s) is a 10.22 fixed-point number.  With E >= |error of s| + |tx_ref - tx| (bounded below from
-// the magnitudes of this cell; tx_ref = what the reference's float64 sequence returns) and
-// dE = d 2^-22, d = ceil(E 2^22) + 2:  if the low 22 bits of int(s) are >= 2d, then
-// n0 + (int(s) >> 22) < tx_ref < n0 + (int(s) >> 22) + 1 strictly - the truncation, and both strict
-// range tests, follow from the integer alone.  Otherwise the pixel is "in doubt" and is recomputed
-// exactly.  Cells where the bound cannot be established (perspective denominators that change sign or
+// with f = f0 + dE: the estimate of tx - n0 shifted up by dE, everything scaled by 2^16 so that
+// F = floor(s) (v_cvt_flr_i32_f32) is a 16.16 fixed-point number whose integer part and fraction are the two
+// 16-bit halves of the register - the anchor add and the doubt test take them through SDWA operand selects,
+// no shift instruction (round 5: 17 instead of 21 vector instructions per pixel; the 10.22 format of rounds 3-4
+// paid two shifts for each).  With E >= |error of s| + |tx_ref - tx| (bounded below from the magnitudes of this
+// cell; tx_ref = what the reference's float64 sequence returns) and dE strictly above E:  v = tx_ref - n0 lies in
+// (s u - 2 dE, s u), u = 2^-16, and s in [F, F + 1), so if the low 16 bits of F are >= ceil(2 dE / u), then
+// n0 + (F >> 16) < tx_ref < n0 + (F >> 16) + 1 strictly - the truncation, and both strict range tests, follow
+// from the integer alone.  Otherwise the pixel is "in doubt" and is recomputed exactly (the window is at least one
+// unit of 2^-16 px wide: 3e-5 of the pixels of C2 / C3, oracle/warp_fast_spec.py).  Cells where the bound cannot be established (perspective denominators that change sign or
 // by more than a quarter across the cell, coordinates beyond 2^30, cells wider than 254 pixels, mesh
 // edges that are not increasing) get a record whose window covers everything: correctness never
 // depends on the estimate.
-constexpr int kFastFracBits = 22;
+constexpr int kFastFracBits = 16;    // 16.16: integer part and fraction are the two halves of the dword (SDWA operand selects)
 constexpr int kFastMaxSpan = 254;   // dx, dy travel as bytes
 
 // anchor of cell index c along one axis: first pixel at or after its lower edge, and how many pixels
@@ -1700,7 +1703,7 @@ __device__ __forceinline__ bool fast_origin_of(double e0, double e1, bool have, 
 // |estimate| - merged into two ints with atomicMin / atomicMax; a cell without a bound claims every row.
 __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok, double xb, double yb, double DX,
                                             double DY, float4 *__restrict__ out, int *src_rows = nullptr) {
-    const double eps64 = 1.1102230246251565e-16, eps32 = 5.9604644775390625e-08, unit = 4194304.0;   // 2^22
+    const double eps64 = 1.1102230246251565e-16, eps32 = 5.9604644775390625e-08, unit = 65536.0;   // 2^16
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa, pc = pa;
     pc.w = __uint_as_float(0xffffffffu);   // window = everything: den = 0 -> s = NaN -> int(s) = 0 < thr
     const double t0b = fma(h[1], yb, h[0] * xb) + h[2];
@@ -1729,10 +1732,11 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
     // float64 side: the reference's own roundings of t0, t2 and of the quotient, the residual R of Q,
     // the roundings of A, B - all <= 16 eps64 (S + (|Q| + Smax)(S2 + |t2b|)) / tmin
     const double E64 = 16.0 * eps64 * (fmax(S0, S1) + (fmax(fabs(Qx), fabs(Qy)) + Smax) * (S2 + at2)) / tmin;
-    const double du = ceil((E32 + E64) * unit) + 2.0;
-    ok = ok && du < 524288.0;            // dE < 1/8; (2 du) << 10 fits 32 bits
+    // the shift: strictly above the bound; the window in units of 2^-16, at least one
+    const double dE = (E32 + E64) * (1.0 + 9.5367431640625e-07) + 9.094947017729282e-13;     // (1 + 2^-20), 2^-40
+    const double t16 = fmax(ceil(2.0 * dE * unit), 1.0);
+    ok = ok && dE < 0.125;               // (NaN fails)
     if (ok) {
-        const double dE = du / unit;
         const double fx = (Qx - n0x) + dE, fy = (Qy - n0y) + dE;
         pa.x = (float)(unit * fma(fx, h[6], Ax));
         pa.y = (float)(unit * fma(fx, h[7], Bx));
@@ -1745,7 +1749,7 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
         pc.x = (float)h[7];
         pc.y = __int_as_float((int)n0x);
         pc.z = __int_as_float((int)n0y);
-        pc.w = __uint_as_float(((unsigned)du * 2u) << (32 - kFastFracBits));
+        pc.w = __uint_as_float((unsigned)t16);
     }
     out[0] = pa;
     out[1] = pb;
@@ -2335,6 +2339,13 @@ __device__ __forceinline__ unsigned gather_px(const uint8_t *__restrict__ img, u
     return (unsigned)__builtin_amdgcn_bitop3_b32((int)v, 0x00ffffff, __builtin_amdgcn_sbfe((int)o, 31u, 1u), 0x40);
 }
 
+// floor(v) as an int32 in ONE instruction (saturating, NaN -> 0): hipcc emits v_floor_f32 + v_cvt_i32_f32 for (int)floorf(v)
+__device__ __forceinline__ int floor_to_int(float v) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // `cr`, `cc`: the pixel's cell row and column as the fast tables give them - the exact table's values unless they
 // point at the extra row / column (then the exact table is read: one more memory round trip, irregular meshes only)
 __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv_pad, const int *__restrict__ lut, int mesh_rows,
@@ -2478,9 +2489,10 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
                 const float num_y = __builtin_fmaf(by[k], dy, ny0[k]);
                 const float den = __builtin_fmaf(h7[k], dy, dn0[k]);
                 const float rc = __builtin_amdgcn_rcpf(den);
-                const int fx = (int)(num_x * rc), fy = (int)(num_y * rc);      // 10.22 fixed point; NaN -> 0
+                const int fx = floor_to_int(num_x * rc), fy = floor_to_int(num_y * rc);      // 16.16 fixed point; NaN -> 0
+                // integer half + anchor, fraction halves: v_add_u32_sdwa (sext WORD_1), v_min_u32_sdwa (WORD_0, WORD_0)
                 const int ix = n0x[k] + (fx >> kFastFracBits), iy = n0y[k] + (fy >> kFastFracBits);
-                const unsigned lo = min((unsigned)fx << (32 - kFastFracBits), (unsigned)fy << (32 - kFastFracBits));
+                const unsigned lo = min((unsigned)fx & 0xffffu, (unsigned)fy & 0xffffu);
                 const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
                 off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
 #if APAP_K3_BUF

@@ -9,7 +9,7 @@ coordinates and recomputes a pixel exactly when the estimate is within a proven 
 integer.  This file restates the record arithmetic and the kernel's float32 operations so that
 ``tests/test_warp_fast_bound.py`` can check, on the CPU, the claim the kernel's exactness rests on:
 
-    for every pixel NOT flagged "in doubt":  anchor + (fixed >> 22) == floor(reference coordinate)
+    for every pixel NOT flagged "in doubt":  anchor + (fixed >> 16) == floor(reference coordinate)
     and the reference coordinate is not an integer,
 
 with the hardware's freedom (``v_rcp_f32`` is accurate to 1 ulp, not correctly rounded) played
@@ -17,7 +17,7 @@ adversarially.
 """
 import numpy as np
 
-FRAC_BITS = 22
+FRAC_BITS = 16          # 16.16 fixed point: integer part and fraction are the two 16-bit halves (SDWA operand selects)
 UNIT = float(1 << FRAC_BITS)
 MAX_SPAN = 254
 EPS64 = 2.0 ** -53
@@ -65,10 +65,14 @@ def record(h, ok, xb, yb, DX, DY):
         good &= Smax < 500.0
         E32 = (6.5 + 3.0 * rho) * EPS32 * Smax
         E64 = 16.0 * EPS64 * (np.maximum(S0, S1) + (np.maximum(np.abs(Qx), np.abs(Qy)) + Smax) * (S2 + at2)) / tmin
-        du = np.ceil((E32 + E64) * UNIT) + 2.0
-        good &= du < 524288.0
-        good &= np.isfinite(du)
-        dE = du / UNIT
+        # the estimate is shifted up by dE, strictly more than its error bound; the conversion is a FLOOR (v_cvt_flr_i32_f32), so
+        # with S = the float32 value, F = floor(S), m = F >> 16, frac = F & 0xffff and v = the reference coordinate - n0:
+        #     v in (S u - 2 dE, S u),  S in [F, F + 1)   =>   m < v < m + 1  as soon as  frac u >= 2 dE   (u = 2^-16)
+        dE = (E32 + E64) * (1.0 + 2.0 ** -20) + 2.0 ** -40
+        thr16 = np.maximum(np.ceil(2.0 * dE * UNIT), 1.0)
+        good &= dE < 0.125
+        good &= np.isfinite(dE)
+        du = 0.5 * thr16              # (half the window in units of 2^-16: what the reports print)
         fx, fy = (Qx - n0x) + dE, (Qy - n0y) + dE
     z = np.zeros_like(t2b)
     f32 = lambda v: np.where(good, v, z).astype(np.float32)   # noqa: E731
@@ -77,7 +81,7 @@ def record(h, ok, xb, yb, DX, DY):
         "ay": f32(UNIT * (fy * h6 + Ay)), "by": f32(UNIT * (fy * h7 + By)), "cy": f32(UNIT * (fy * t2b)),
         "t2b": f32(t2b), "h6": f32(h6), "h7": f32(h7),
         "n0x": np.where(good, n0x, 0).astype(np.int64), "n0y": np.where(good, n0y, 0).astype(np.int64),
-        "thr": np.where(good, (2 * np.where(good, du, 0)).astype(np.int64) << (32 - FRAC_BITS), 0xffffffff).astype(np.int64),
+        "thr": np.where(good, np.where(good, thr16, 0).astype(np.int64), 0xffffffff).astype(np.int64),
         "good": good, "E": np.where(good, E32 + E64, np.inf), "du": np.where(good, du, np.inf),
     }
 
@@ -101,11 +105,11 @@ def estimate(rec, dx, dy, rcp_ulps=0):
         rc = np.where(np.isfinite(rc), rc + np.spacing(np.abs(rc)) * np.asarray(rcp_ulps, np.float32), rc).astype(np.float32)
         sx, sy = (nx * rc).astype(np.float32), (ny * rc).astype(np.float32)
 
-        def to_int(v):     # v_cvt_i32_f32: truncation, saturating, NaN -> 0
+        def to_int(v):     # v_cvt_flr_i32_f32: floor, saturating, NaN -> 0
             v = np.where(np.isnan(v), np.float32(0), v)
-            return np.clip(np.trunc(v.astype(np.float64)), -2147483648.0, 2147483647.0).astype(np.int64)
+            return np.clip(np.floor(v.astype(np.float64)), -2147483648.0, 2147483647.0).astype(np.int64)
         fx, fy = to_int(sx), to_int(sy)
-    lo = np.minimum((fx << (32 - FRAC_BITS)) & 0xffffffff, (fy << (32 - FRAC_BITS)) & 0xffffffff)
+    lo = np.minimum(fx & 0xffff, fy & 0xffff)        # the fractions: the low halves (two's complement: floor semantics)
     doubt = lo < rec["thr"]
     return rec["n0x"] + (fx >> FRAC_BITS), rec["n0y"] + (fy >> FRAC_BITS), doubt
 
