@@ -5,6 +5,7 @@
 //   loads    G4   four dword gathers per lane and row at the pixels' byte offsets (today's kernel)
 //            W16  one unaligned 16-byte window per lane and row
 //            D3   one unaligned 12-byte load per lane and row
+//            G4A  four ALIGNED 8-byte loads per lane and row (the two dwords around each pixel), pixel cut out with v_alignbyte
 //   stores   U12  one unaligned 12-byte store per lane and row (today's kernel)
 //            A16  the row's 768 bytes re-laid through LDS: 48 lanes store one ALIGNED 16-byte piece, head / tail bytes of
 //                 the row segment by one byte store
@@ -43,7 +44,7 @@ struct __attribute__((packed, aligned(4))) D12 { unsigned a, b, c; };
 struct __attribute__((packed, aligned(1))) B16 { unsigned a, b, c, d; };
 struct __attribute__((packed, aligned(4))) W5 { unsigned a, b, c, d, e; };
 
-enum { G4 = 0, W16 = 1, D3 = 2, ZERO = 3 };
+enum { G4 = 0, W16 = 1, D3 = 2, ZERO = 3, G4A = 4 };
 enum { U12 = 0, A16 = 1, SD12 = 2, NONE = 3 };
 
 constexpr int kRows = 4;
@@ -83,6 +84,18 @@ __global__ __launch_bounds__(256) void k_copy(const uint8_t *__restrict__ img, i
         }
         if (L == ZERO) {     // no loads at all: the store pattern's own time
             px[t][0] = o[0]; px[t][1] = o[1] ^ o[2]; px[t][2] = o[3];
+        } else if (L == G4A) {
+            unsigned p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned oc = o[k] < last ? o[k] : last;
+                const uint2 v2 = *reinterpret_cast<const uint2 *>(img + (oc & ~3u));       // dword-aligned, 8 bytes
+                const unsigned v = __builtin_amdgcn_alignbyte(v2.y, v2.x, oc & 3u);
+                p[k] = (unsigned)__builtin_amdgcn_bitop3_b32((int)v, 0x00ffffff, __builtin_amdgcn_sbfe((int)o[k], 31u, 1u), 0x40);
+            }
+            px[t][0] = p[0] | (p[1] << 24);
+            px[t][1] = __builtin_amdgcn_perm(p[2], p[1], 0x05040201u);
+            px[t][2] = __builtin_amdgcn_perm(p[3], p[2], 0x06050402u);
         } else if (L == G4) {
             unsigned p[4];
 #pragma unroll
@@ -338,6 +351,8 @@ int main(int argc, char **argv) {
     RUN(D3, A16);
     RUN(D3, SD12);
     RUN(D3, NONE);
+    RUN(G4A, U12);
+    RUN(G4A, NONE);
     RUN(ZERO, U12);
     RUN(ZERO, A16);
     RUN(ZERO, SD12);
