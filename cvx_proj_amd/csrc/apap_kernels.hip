@@ -2364,12 +2364,6 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
 #ifndef APAP_K3_BUF
 #define APAP_K3_BUF 0
 #endif
-#ifndef APAP_K3_W16
-#define APAP_K3_W16 0
-#endif
-#ifndef APAP_K3_BLOCK
-#define APAP_K3_BLOCK 256
-#endif
 #ifndef APAP_K3_WAVES_ATTR
 #define APAP_K3_WAVES_ATTR
 #endif
@@ -2551,7 +2545,9 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         }
     }
     // all of the strip's gathers in flight together (issuing a row's as soon as its offsets exist, or dropping
-    // the range tests and the last-pixel guard for waves wholly inside the source, measured no faster: DESIGN.md)
+    // the range tests and the last-pixel guard for waves wholly inside the source, measured no faster: DESIGN.md;
+    // one 16-byte window load per lane and row with the gathers kept for the lanes it cannot serve: byte-identical
+    // and 20-26 % slower, profiles/r05_k3_experiments.txt 2b)
 #if APAP_K3_BUF
     {
         // source pixels through a buffer descriptor over the image: the range check returns 0 for the "outside" marker, so a
@@ -2569,45 +2565,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
             for (int t = 0; t < kRows; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) px[t][k] = ((patch >> (t * 4 + k)) & 1u) ? last_px : px[t][k];
-        }
-    }
-#elif APAP_K3_W16
-    {
-        // EXPERIMENT: one 16-byte window per lane and row where the lane's four source pixels lie inside
-        // 16 bytes from the first one (the common case: same source row, steps of 0-4 pixels), the four dword gathers only for
-        // the lanes that do not (a source row boundary inside the group, pixels outside the source, the image's last bytes).
-        // The pixels are cut out of the window through a wave-private LDS slot (ds_read_b32 at a byte offset); lanes that
-        // gathered leave their four pixels in the same slot, so that one extraction serves both.
-        __shared__ __attribute__((aligned(16))) unsigned s_win[APAP_K3_BLOCK / 64][kRows][64 * 4 + 4];     // (+ 4: a pixel at byte 13 of the last slot reads one byte on)
-        const unsigned last16 = last + 4u - 16u;          // the last byte offset a 16-byte load may start at
-        unsigned code[kRows];       // byte positions of pixels 1..3 inside the slot: d1 | d2 << 8 | d3 << 16
-#pragma unroll
-        for (int t = 0; t < kRows; ++t) {
-            const unsigned A = off[t][0];
-            const unsigned d1 = off[t][1] - A, d2 = off[t][2] - A, d3 = off[t][3] - A;
-            const bool win = (A <= last16) & (max(max(d1, d2), d3) <= 13u);
-            code[t] = win ? (d1 | (d2 << 8) | (d3 << 16)) : (4u | (8u << 8) | (12u << 16));
-            if (win) {
-                const uint4 w = *reinterpret_cast<const uint4 *>(img + A);       // (byte address: global_load_dwordx4)
-                px[t][0] = w.x; px[t][1] = w.y; px[t][2] = w.z; px[t][3] = w.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < kRows; ++t) {
-            unsigned *slot = &s_win[wave][t][lane * 4];
-            *reinterpret_cast<uint4 *>(slot) = make_uint4(px[t][0], px[t][1], px[t][2], px[t][3]);
-        }
-#pragma unroll
-        for (int t = 0; t < kRows; ++t) {
-            const uint8_t *slot = reinterpret_cast<const uint8_t *>(&s_win[wave][t][lane * 4]);
-            unsigned v1, v2, v3;
-            __builtin_memcpy(&v1, slot + (code[t] & 0xffu), 4);
-            __builtin_memcpy(&v2, slot + ((code[t] >> 8) & 0xffu), 4);
-            __builtin_memcpy(&v3, slot + (code[t] >> 16), 4);
-            px[t][0] &= 0x00ffffffu; px[t][1] = v1 & 0x00ffffffu; px[t][2] = v2 & 0x00ffffffu; px[t][3] = v3 & 0x00ffffffu;
         }
     }
 #else
