@@ -67,7 +67,8 @@ def main():
         torch.cuda.synchronize()
         if ref is None:
             ref = outs[0].clone()
-        assert torch.equal(outs[0], ref), f"{form}: canvas differs from the first form's"
+        timing_only = os.environ.get("APAP_AB_TIMING_ONLY") == "1"      # ablation builds (tools/ab_forms.sh): wrong pixels on purpose
+        assert timing_only or torch.equal(outs[0], ref), f"{form}: canvas differs from the first form's"
         res = {"config": a.config, "form": form, "rows": a.rows or p.final_h}
         for mode, n in (("warm", 1), ("cold", nsets)):
             t0 = time.perf_counter()
@@ -94,7 +95,7 @@ def main():
                 launch(i % n, N.WARP_ALL)
             torch.cuda.synchronize()
             res[f"{mode}_step_with_setup_us"] = round((time.perf_counter() - t0) / a.steps * 1e6, 2)
-        assert int(st.cpu()[0]) == 0
+        assert timing_only or int(st.cpu()[0]) == 0
         print(json.dumps(res), flush=True)
         ctx.close()
 
