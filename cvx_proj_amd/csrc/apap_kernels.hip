@@ -2364,12 +2364,6 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
 #ifndef APAP_K3_BUF
 #define APAP_K3_BUF 0
 #endif
-#ifndef APAP_K3_W2
-#define APAP_K3_W2 0
-#endif
-#ifndef APAP_K3_BLOCK
-#define APAP_K3_BLOCK 256
-#endif
 #ifndef APAP_K3_WAVES_ATTR
 #define APAP_K3_WAVES_ATTR
 #endif
@@ -2552,8 +2546,8 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
     }
     // all of the strip's gathers in flight together (issuing a row's as soon as its offsets exist, or dropping
     // the range tests and the last-pixel guard for waves wholly inside the source, measured no faster: DESIGN.md;
-    // one 16-byte window load per lane and row with the gathers kept for the lanes it cannot serve: byte-identical
-    // and 20-26 % slower, profiles/r05_k3_experiments.txt 2b)
+    // one 16-byte window load per lane and row with the gathers kept for the lanes it cannot serve, and two 12-byte
+    // windows per lane and row for every lane: byte-identical and 13-26 % slower, profiles/r05_k3_experiments.txt 2b, 2c)
 #if APAP_K3_BUF
     {
         // source pixels through a buffer descriptor over the image: the range check returns 0 for the "outside" marker, so a
@@ -2571,60 +2565,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
             for (int t = 0; t < kRows; ++t)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) px[t][k] = ((patch >> (t * 4 + k)) & 1u) ? last_px : px[t][k];
-        }
-    }
-#elif APAP_K3_W2
-    {
-        // EXPERIMENT: two 12-byte windows per lane and row, UNIFORMLY - A at the first pixel's byte offset, B ending with the
-        // last pixel's three bytes - so that a lane whose four source pixels form one or two runs (the common case, and the
-        // lanes that straddle a source row) needs no per-pixel gather: 8 vector-memory instructions per strip instead of 16,
-        // half the address-path work.  Pixels 0 and 3 sit in fixed registers (A's first dword, B's last); pixels 1 and 2
-        // are cut out of the lane's 24-byte LDS slot at a byte offset.  Lanes the windows cannot serve (pixels outside the
-        // source, the image's first / last bytes, steps of more than 3 pixels) gather as before, under a wave-uniform branch.
-        __shared__ __attribute__((aligned(8))) unsigned s_win[APAP_K3_BLOCK / 64][64 * 6 + 2];
-        const bool room = last + 4u >= 12u;               // (an image of fewer than 12 bytes: every lane gathers)
-        const unsigned last12 = room ? last + 4u - 12u : 0u;     // the last byte offset a 12-byte load may start at
-        typedef unsigned Dwords3 __attribute__((ext_vector_type(3)));
-        typedef Dwords3 Dwords3AnyByte __attribute__((aligned(1)));
-        unsigned wa[kRows][3], wb[kRows][3], code[kRows];
-        unsigned long long fallback = 0;
-#pragma unroll
-        for (int t = 0; t < kRows; ++t) {
-            const unsigned A = off[t][0], B = off[t][3] - 8u;
-            const unsigned d1 = off[t][1] - A, d2 = off[t][2] - A, d3 = off[t][3] - A;
-            const unsigned c = 20u - d3;                  // byte A + d sits at slot offset d + c when it is taken from B (slot bytes 12-23)
-            const unsigned e1 = d1 + c, e2 = d2 + c;
-            const bool a1 = d1 <= 9u, a2 = d2 <= 9u;
-            const bool ok = room & (A <= last12) & (B <= last12) & (a1 | (e1 - 12u <= 9u)) & (a2 | (e2 - 12u <= 9u));
-            code[t] = ok ? ((a1 ? d1 : e1) | ((a2 ? d2 : e2) << 8)) : (4u | (8u << 8));
-            const unsigned long long bad = __builtin_amdgcn_ballot_w64(!ok);
-            fallback |= bad;
-            wa[t][0] = wa[t][1] = wa[t][2] = wb[t][0] = wb[t][1] = wb[t][2] = 0u;
-            if (ok) {
-                const Dwords3 va = *reinterpret_cast<const Dwords3AnyByte *>(img + A);
-                const Dwords3 vb = *reinterpret_cast<const Dwords3AnyByte *>(img + B);
-                wa[t][0] = va.x; wa[t][1] = va.y; wa[t][2] = va.z;
-                wb[t][0] = vb.x; wb[t][1] = vb.y; wb[t][2] = vb.z;
-            }
-            if (bad != 0ull) {      // wave-uniform: some lane of this row gathers its four pixels
-                if (!ok) {
-                    wa[t][0] = gather_px(img, off[t][0], last);
-                    wa[t][1] = gather_px(img, off[t][1], last);
-                    wa[t][2] = gather_px(img, off[t][2], last);
-                    wb[t][2] = gather_px(img, off[t][3], last);
-                }
-            }
-        }
-        uint8_t *slot = reinterpret_cast<uint8_t *>(&s_win[wave][lane * 6]);
-#pragma unroll
-        for (int t = 0; t < kRows; ++t) {
-            struct __attribute__((packed, aligned(8))) Slot { unsigned v[6]; };
-            Slot sv = {{wa[t][0], wa[t][1], wa[t][2], wb[t][0], wb[t][1], wb[t][2]}};
-            __builtin_memcpy(slot, &sv, 24);
-            unsigned v1, v2;
-            __builtin_memcpy(&v1, slot + (code[t] & 0xffu), 4);
-            __builtin_memcpy(&v2, slot + (code[t] >> 8), 4);
-            px[t][0] = wa[t][0] & 0x00ffffffu; px[t][1] = v1 & 0x00ffffffu; px[t][2] = v2 & 0x00ffffffu; px[t][3] = wb[t][2] & 0x00ffffffu;
         }
     }
 #else
