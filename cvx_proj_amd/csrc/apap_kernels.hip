@@ -525,10 +525,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
     for (int i = 0; i < 4; ++i) {
         const int ci = cell_base + 4 * i;
         if (ci < cells_pad) {  // an 8-wave block may overhang the padded cell count
-            // non-temporal: the slab is read back by ANOTHER kernel (K2), from whichever XCD its wave lands on - nothing gains from
-            // its 19 MB sitting dirty in this XCD's L2 until the kernel's end (K1 150.0 -> 148.7 us at C3, three A/B rounds)
-            __builtin_nontemporal_store(acc0[i], &slab[(size_t)col * cells_pad + ci]);
-            if (col < kMoments - 16) __builtin_nontemporal_store(acc1[i], &slab[(size_t)(16 + col) * cells_pad + ci]);
+            // (plain stores: non-temporal ones were measured - K1 150.0 -> 148.7 us, but the 128-byte pieces of a moment row no
+            // longer merge in the L2 and WRITE_SIZE grows from 18.8 to 34.1 MB per launch, profiles/r05_solve_experiments.txt)
+            slab[(size_t)col * cells_pad + ci] = acc0[i];
+            if (col < kMoments - 16) slab[(size_t)(16 + col) * cells_pad + ci] = acc1[i];
         }
     }
 }
