@@ -1671,7 +1671,8 @@ constexpr int kMaxEdges = 4096;  // per axis; larger meshes take the linear-scan
 // (s u - 2 dE, s u), u = 2^-16, and s in [F, F + 1), so if the low 16 bits of F are >= ceil(2 dE / u), then
 // n0 + (F >> 16) < tx_ref < n0 + (F >> 16) + 1 strictly - the truncation, and both strict range tests, follow
 // from the integer alone.  Otherwise the pixel is "in doubt" and is recomputed exactly (the window is at least one
-// unit of 2^-16 px wide: 3e-5 of the pixels of C2 / C3, oracle/warp_fast_spec.py).  Cells where the bound cannot be established (perspective denominators that change sign or
+// unit of 2^-16 px wide: 3e-5 of the pixels of C2 / C3, oracle/warp_fast_spec.py).
+// Cells where the bound cannot be established (perspective denominators that change sign or
 // by more than a quarter across the cell, coordinates beyond 2^30, cells wider than 254 pixels, mesh
 // edges that are not increasing) get a record whose window covers everything: correctness never
 // depends on the estimate.
