@@ -643,7 +643,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture the solve and the warp step into HIP graphs and time graph replays")
     ap.add_argument("--want-waves", type=int, help="tuning: APAP_OPT_WANT_WAVES of the context (K1 keypoint splits)")
-    ap.add_argument("--warp-rows", type=int, choices=[0, 2, 4, 8], help="tuning: APAP_OPT_WARP_ROWS (0 = flat-order warp kernel)")
+    ap.add_argument("--warp-rows", type=int, choices=[0, 1, 2, 4, 5, 6, 8], help="APAP_OPT_WARP_ROWS (1 = chosen from the size of the launch: the default; 0 = flat-order warp kernel)")
     ap.add_argument("--warp-fast", type=int, choices=[0, 1], help="tuning: APAP_OPT_WARP_FAST (0 = float64 for every pixel of K3)")
     ap.add_argument("--fused-max-cells", type=int, help="tuning: APAP_OPT_FUSED_MAX_CELLS (fused K1 + K2 launch for small meshes)")
     ap.add_argument("--cold-mb", type=float, default=640.0,

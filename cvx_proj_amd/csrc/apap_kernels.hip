@@ -2767,7 +2767,7 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_CAREFUL:
         case APAP_OPT_PROFILE: ok = value == 0 || value == 1; break;
         case APAP_OPT_WANT_WAVES: ok = value >= 1; break;
-        case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 2 || value == 4 || value == 8; break;
+        case APAP_OPT_WARP_ROWS: ok = value == 0 || value == 1 || value == 2 || value == 4 || value == 5 || value == 6 || value == 8; break;
         case APAP_OPT_WEIGHT_CHUNK_KB: ok = value >= 1; break;
         case APAP_OPT_FUSED_MAX_CELLS:
         case APAP_OPT_PLAN_CELLS: ok = value >= 0; break;
@@ -3078,10 +3078,19 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
     const WarpStrides st{a.img_stride, a.out_stride, a.center_stride, ww.hinv_stride, ww.frec_stride};
     const size_t total = (size_t)final_w * row_count;
     const size_t threads = (total + 3) / 4;
-    // APAP_OPT_WARP_ROWS (experiments): 0 = flat-order kernel, 2 / 4 / 8 = row strips of that many
-    // rows per wave.  Default 4: 3 / 4 / 5 / 6 measured within 2 % of each other at C3, 2 and 8 are
-    // 8-10 % slower.
-    const int warp_kernel = apap::opt(ctx, APAP_OPT_WARP_ROWS);
+    // APAP_OPT_WARP_ROWS: 0 = flat-order kernel, 2 / 4 / 5 / 6 / 8 = row strips of that many rows per wave, 1 (default) =
+    // chosen from the size of the launch.  A strip pays its table trips and its cell records once, so taller strips are
+    // cheaper per pixel - but a launch needs a few generations of waves before that shows: measured on the final kernel
+    // (profiles/r05_k3_experiments.txt 7), one C3 canvas (1.3 generations of 4-row strips) runs 14.9 us with 4 or 5 rows,
+    // 15.3 with 6, 16.2 with 8; C4's canvas (5 generations) 45.1 / 43.9 / 43.7 / 44.6; 32 C5 pairs per launch 13.0 / 12.1 /
+    // 12.7 / 11.9 us per pair; 8 C3 pairs 11.2 / 11.0 / 10.9 / 10.7.  The fused stitch keeps 4 rows (its taller forms need
+    // more registers: one C3 stitch 32.8 us with 4 rows, 34.4 with 5, 37.2 with 6).
+    int warp_kernel = apap::opt(ctx, APAP_OPT_WARP_ROWS);
+    if (warp_kernel == 1) {
+        const unsigned long long strips4 = (unsigned long long)batch * (unsigned long long)((final_w + 255) / 256) *
+                                           (unsigned long long)((row_count + 3) / 4);      // waves of a 4-row launch
+        warp_kernel = d_center ? 4 : strips4 >= 64000ull ? 8 : strips4 >= 24000ull ? 6 : 4;
+    }
     // the strip kernel forms source offsets with 24-bit multiplies
     // ... and marks pixels outside the source with the sign bit of the byte offset
     const bool strips = warp_kernel > 0 && img_w < (1 << 24) && img_h < (1 << 24) &&
@@ -3093,7 +3102,7 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
                          final_h / mesh_rows <= 128;
     if (fast_ok) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
-        const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? 4 : 2;
+        const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? warp_kernel : 2;       // instantiated for 2, 4, 5, 6, 8
 #ifndef APAP_K3_BLOCK
 #define APAP_K3_BLOCK 256
 #endif
@@ -3109,7 +3118,9 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
                            (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st, a.status)
         if (rows == 4) { APAP_LAUNCH_FAST(4); }
-        else if (rows == 8) { APAP_LAUNCH_FAST(8); }
+        else if (rows == 5) { APAP_LAUNCH_FAST(5); }
+        else if (rows == 6) { APAP_LAUNCH_FAST(6); }
+        else if (rows >= 7) { APAP_LAUNCH_FAST(8); }
         else { APAP_LAUNCH_FAST(2); }
 #undef APAP_LAUNCH_FAST
     } else if (strips) {

@@ -108,7 +108,10 @@ typedef struct apap_ctx apap_ctx;
                                      one-sided Jacobi) as apap.py:159-161 does; 0: normal equations only    */
 #define APAP_OPT_PROFILE 3        /* 1: bracket every kernel with HIP events (apap_ctx_profile_read)     */
 #define APAP_OPT_WANT_WAVES 4     /* tuning: waves K1 aims at before it stops splitting the keypoints     */
-#define APAP_OPT_WARP_ROWS 5      /* tuning: canvas rows per wave of K3 (2, 4, 8; 0 = flat-order kernel)  */
+#define APAP_OPT_WARP_ROWS 5      /* canvas rows per wave of K3: 1 (default) = chosen from the size of the launch (4 for one
+                                     4K canvas and for the fused stitch, 6 for an 8K canvas, 8 for batches of many
+                                     canvases); 2, 4, 5, 6, 8 = that many; 0 = the flat-order kernel.  Same canvas bytes in
+                                     every form                                                                             */
 #define APAP_OPT_WEIGHT_CHUNK_KB 6 /* device staging of the optional weight tensor, KiB (default 1 GiB)   */
 #define APAP_OPT_FUSED_MAX_CELLS 7 /* tuning: meshes of up to this many cells (x batch) take the fused K1 + K2
                                       launch when the variant is AUTO (default 4096; 0 = never)             */

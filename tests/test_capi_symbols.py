@@ -42,7 +42,7 @@ def test_contexts_hold_the_options_not_the_process(native):
     a = native.Context(variant=native.VARIANT_VALU, eigen=native.EIGEN_JACOBI)
     b = native.Context()
     assert (a.get("variant"), a.get("eigen"), a.get("careful")) == (native.VARIANT_VALU, native.EIGEN_JACOBI, 1)
-    assert (b.get("variant"), b.get("eigen"), b.get("careful"), b.get("warp_rows")) == (native.VARIANT_AUTO, native.EIGEN_AUTO, 1, 4)
+    assert (b.get("variant"), b.get("eigen"), b.get("careful"), b.get("warp_rows")) == (native.VARIANT_AUTO, native.EIGEN_AUTO, 1, 1)
     v = ctypes.c_int(-1)
     assert native.lib().apap_ctx_get_option(None, native.OPT_WANT_WAVES, ctypes.byref(v)) == native.OK and v.value == 4096
     assert native.lib().apap_ctx_set_option(None, native.OPT_CAREFUL, 0) == native.ERR_INVALID_ARG      # NULL cannot be changed

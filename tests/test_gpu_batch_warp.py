@@ -77,7 +77,7 @@ def test_c5_batched_warp_vs_reference(native, golden):
         assert torch.equal(out[k], canv[k])
 
 
-@pytest.mark.parametrize("rows_per_wave,fast", [(4, 1), (2, 1), (8, 1), (4, 0), (0, 1)])
+@pytest.mark.parametrize("rows_per_wave,fast", [(1, 1), (4, 1), (2, 1), (5, 1), (6, 1), (8, 1), (4, 0), (0, 1)])
 def test_batched_warp_equals_per_pair_launches(native, rows_per_wave, fast):
     """Every kernel form (float32-estimate strips, all-float64 strips, flat order) with grid.z = pair: the canvases
     and the inverses of a batch equal one call per pair, which equal the oracle."""
@@ -264,7 +264,7 @@ def test_gather_on_an_unprepared_workspace_reports_and_touches_nothing(native):
     ref, _ = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
     img = torch.from_numpy(p.img).to(dev)
     Hd = torch.from_numpy(H.reshape(-1, 9)).to(dev)
-    forms = [dict(), dict(warp_rows=2), dict(warp_rows=8), dict(warp_fast=0), dict(warp_rows=0)]
+    forms = [dict(), dict(warp_rows=2), dict(warp_rows=4), dict(warp_rows=6), dict(warp_rows=8), dict(warp_fast=0), dict(warp_rows=0)]
     for opts in forms:
         ctx = native.Context(**opts)
         try:

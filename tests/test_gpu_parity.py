@@ -839,7 +839,7 @@ def test_batched_solve_equals_separate_solves(native):
         assert torch.equal(H2[k], Hk), k
 
 
-@pytest.mark.parametrize("rows_per_wave,fast", [(0, 1), (2, 1), (8, 1), (2, 0), (4, 0), (8, 0)])
+@pytest.mark.parametrize("rows_per_wave,fast", [(0, 1), (2, 1), (4, 1), (5, 1), (6, 1), (8, 1), (2, 0), (4, 0), (8, 0)])
 def test_other_warp_kernel_forms_still_match(native, golden, rows_per_wave, fast):
     """The flat-order kernel (0) is the fallback for sources the strip kernels do not take (a side of
     2^24 pixels, 2 GiB); strips of 2 and 8 rows are the other instantiations; APAP_OPT_WARP_FAST = 0 is the
