@@ -238,7 +238,7 @@ def test_fuzz_ransac(native, seed):
 def test_fuzz_resident_forms(native, seed):
     """The forms round 4 added, on the random cases above (any mesh shape, 5 ... 2500 keypoints, gamma = 0 included, strong
     perspective, singular or non-finite cells replaced as in test_fuzz_solve_and_warp): the solve whose tail leaves the cells
-    warp ready gives the plain solve's grid and the set-up kernel's workspace bytes; the gather on it - strips of 4 and of 2 / 8 rows,
+    warp ready gives the plain solve's grid and the set-up kernel's workspace bytes; the gather on it - strips of 4 and of 2 / 5 / 6 / 8 rows,
     a batch of two pairs, a row band - gives the host-buffer call's canvas (itself checked against the oracle above)."""
     import torch
     from cvx_proj_amd.dist import WarpPlan, hip_solve_batch
@@ -274,7 +274,7 @@ def test_fuzz_resident_forms(native, seed):
     want0, _ = native.local_warp(c["img"], Hn, c["mesh"][0], c["mesh"][1], fw, fh, ox, oy)
     want1, _ = native.local_warp(np.ascontiguousarray(c["img"][::-1]), Hn, c["mesh"][0], c["mesh"][1], fw, fh, ox, oy)
     Hd = t(np.stack([Hn, Hn]).reshape(-1, 9))
-    rows8 = native.Context(warp_rows=8 if seed % 2 else 2)
+    rows8 = native.Context(warp_rows=(2, 5, 6, 8)[seed % 4])        # the strip heights the default (4, or chosen from the launch's size) does not take here
     try:
         for ctx in (None, rows8):
             p2 = WarpPlan(c["mesh"], (rows, cols), fw, fh, ox, oy, dev, batch=2, ctx=ctx)
