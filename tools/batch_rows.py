@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""K3 per pair against the strip height (APAP_OPT_WARP_ROWS = 4 / 5 / 6 / 8) for a batch of pairs in one launch (WarpPlan.gather,
+launches back to back).  profiles/r05_k3_experiments.txt item 7.      python tools/batch_rows.py C5 32"""
 import sys, os, json, ctypes, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
