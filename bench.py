@@ -86,14 +86,15 @@ class Resident:
         self.pair = pair
         self.batch = batch
         self.ctx = N._h(ctx)
+        moments = ctx.get("moments") if ctx is not None else 30      # the table's layout follows the context (APAP_OPT_MOMENTS)
         q = N.host_prepare(pair.src, pair.dst)
-        table = N.host_build_table(pair.src, q["cf1"], q["cf2"])
+        table = N.host_build_table(pair.src, q["cf1"], q["cf2"], moments=moments)
         den = N.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
         if batch > 1:      # independent keypoint sets (different seeds), same mesh
             tabs, dens = [table], [den]
             for extra in seed_pairs:
                 qe = N.host_prepare(extra.src, extra.dst)
-                tabs.append(N.host_build_table(extra.src, qe["cf1"], qe["cf2"]))
+                tabs.append(N.host_build_table(extra.src, qe["cf1"], qe["cf2"], moments=moments))
                 dens.append(N.host_build_denorm(qe["iC2"], qe["C1"], qe["iN2"], qe["N1"]))
             table, den = np.stack(tabs), np.stack(dens)
         self.n = len(pair.src)
@@ -600,9 +601,11 @@ def roofline_k2(config, res, kern, kern_plain, tj, fused):
     algo_plain = cells * (splits * 240 + 16 + 36)
     # the tail: + 2 x 2 edge doubles read, + 10 doubles of padded inverse and a 48-byte record written
     algo_ready = algo_plain + cells * (32 + 80 + 48)
-    out = {"kernel": "k_eigen_denorm", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "keypoint_splits": int(splits),
-           "note": "one wave per SIMD walking a ~900-instruction dependent chain per cell: bound by that chain, not by bytes - the "
-                   "fraction says how little of the HBM a launch of 625 waves can ask for.  A single slab (no keypoint splits: K2 reads "
+    out = {"kernel": "k_eigen_denorm", "bound": "latency", "priced_against": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "keypoint_splits": int(splits),
+           "note": "one wave per SIMD walking a ~900-instruction dependent chain per cell: bound by that chain's latency, not by bytes "
+                   "or flops - the fraction (bytes over the kernel's time against HBM) says how little of the HBM a launch of 625 waves "
+                   "can ask for.  A single slab (no keypoint splits: K2 reads "
                    "half) was measured: K2 -0.7 us, K1 +32 us (625 blocks on 256 CUs), profiles/r05_summary.txt"}
     for tag, ms, algo in (("plain", kern_plain.get("eigen"), algo_plain), ("warp_ready", kern.get("eigen"), algo_ready)):
         if not ms:
@@ -611,6 +614,99 @@ def roofline_k2(config, res, kern, kern_plain, tj, fused):
         out[tag] = {"kernel_ms": ms, "timing": "a pair of HIP events per launch (+ ~2 us of event handling)",
                     "algorithmic_bytes": int(algo), "achieved": algo / (ms * 1e-3) / 1e9, "frac": algo / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                     "traffic": counter, "traffic_gbs": None if counter is None else counter / (ms * 1e-3) / 1e9}
+    return out
+
+
+def small_config(cfg, dev, stream, steps, timed, condition, back_to_back):
+    """One of BASELINE's other single-GPU configurations (C1, C2) on the same definitions as the headline: the resident step
+    (solve with the warp-ready tail, gather-only warp), exactly `steps` steps each, kernel times by HIP events."""
+    ctx = N.Context()
+    pair = config_pair(cfg)
+    res = Resident(pair, dev, ctx=ctx)
+    condition(lambda: res.solve(stream))
+    for _ in range(5):
+        res.solve(stream)
+        res.warp(stream)
+    t_solve = timed(lambda: res.solve(stream), steps)
+    t_warp = timed(lambda: res.warp(stream), steps)
+    assert int(res.status.cpu()[0]) == 0
+    ctx.set("profile", 1)
+    for _ in range(steps):
+        res.solve(stream)
+        res.warp(stream)
+    torch.cuda.synchronize()
+    kern = read_kernel_ms(ctx)
+    ctx.set("profile", 0)
+    k1_ms = back_to_back(lambda: res.solve(stream), max(steps, 50))      # the solve's launches back to back (K1 + K2, or the fused one)
+    k3_ms = back_to_back(lambda: res.warp(stream), max(steps, 50))
+    fused = res.cells <= ctx.get("fused_max_cells")
+    flops = K1_FLOPS_PER_CELL_POINT * res.n * res.cells
+    nz = int((res.out.view(-1, 3).amax(dim=1) > 0).sum().cpu())
+    wbytes = 6 * nz + 3 * (pair.final_w * pair.final_h - nz)
+    out = {"workload": f"{cfg}: {CONFIGS[cfg][0]}x{CONFIGS[cfg][1]} pair, {res.n} correspondences, {res.rows}x{res.cols} mesh, canvas "
+                       f"{pair.final_w}x{pair.final_h}",
+           "value": res.cells * steps / t_solve, "unit": "homographies/s", "solve_ms_per_step": t_solve / steps * 1e3,
+           "warp": {"value": pair.final_w * pair.final_h * steps / t_warp / 1e6, "unit": "Mpix/s", "ms_per_step": t_warp / steps * 1e3},
+           "solve_launch": "k_solve_small (K1 + K2 fused, one launch)" if fused else "k_assemble_mfma + k_eigen_denorm",
+           "kernels_ms": {k: kern.get(k) for k in ("assemble", "eigen", "warp")},
+           "solve_ms_back_to_back": k1_ms, "warp_ms_back_to_back": k3_ms,
+           "roofline": {"kernel": "k_solve_small (the K2 tail is inside the time, only K1's flops are counted)" if fused else "k_assemble_mfma",
+                        "bound": "latency" if fused else "mfma", "priced_against": "mfma", "achieved": flops / (kern["assemble"] * 1e-3) / 1e12,
+                        "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": flops / (kern["assemble"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS},
+           "roofline_warp": {"kernel": "k_warp_fast", "cache": "warm", "bound": "hbm", "achieved": wbytes / (k3_ms * 1e-3) / 1e9,
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": wbytes / (k3_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "kernel_ms": k3_ms},
+           "note": "small launches: a few microseconds of kernel behind ~4-5 us of launch, first table trips and last stores - the "
+                   "fractions say how much of the chip one such launch can use, not how good the kernel is at size (C3, C4 and the "
+                   "batched C5 are the same kernels at size)"}
+    del res
+    ctx.close()
+    return out
+
+
+def opt_in_modes(cfg, pair, dev, stream, steps, timed, condition, H_default, k1_default_ms):
+    """The opt-in forms of the solve (APAP_OPT_MOMENTS = 24, alone and with APAP_OPT_WEIGHTS_F32) beside the default, same
+    configuration and step definition (the resident step's solve).  NOT bit-identical (tests/test_gpu_moments24.py): the object
+    says by how much.  `value` of the line stays the default's."""
+    def rmse_delta(Ha, Hb, pts):
+        """north_star's measure: per cell, the RMS over keypoints of |proj(Ha, p) - proj(Hb, p)| (pixels)."""
+        q = np.concatenate([pts.astype(np.float64), np.ones((len(pts), 1))], axis=1)
+        pa, pb = (np.einsum("rcij,kj->rcki", H.astype(np.float64), q) for H in (Ha, Hb))
+        pa, pb = pa[..., :2] / pa[..., 2:3], pb[..., :2] / pb[..., 2:3]
+        return np.sqrt(((pa - pb) ** 2).sum(axis=-1).mean(axis=-1))
+    out = {"note": "24 sums of the exact products instead of the 30 that keep apap.py:103-119's float32-rounded products: one "
+                   "v_mfma_f64_16x16x4_f64 + two v_mfma_f64_4x4x4_4b_f64 per 4-keypoint step instead of two 16x16x4 (VERDICT r5 item "
+                   "1: predicted K1 149 -> ~131 us, value +10-13 %); weights_f32 = the same with w^2 evaluated in float32.  Opt-in: "
+                   "grids differ from the reference's by one float32 ulp here and there; the headline `value` is the bit-identical "
+                   "default", "k1_default_ms": k1_default_ms}
+    for tag, opts in (("fp64_weights", {"moments": 24}), ("f32_weights", {"moments": 24, "weights_f32": 1})):
+        ctx = N.Context(**opts)
+        res = Resident(pair, dev, ctx=ctx)
+        condition(lambda: res.solve(stream))
+        for _ in range(5):
+            res.solve(stream)
+        t = timed(lambda: res.solve(stream), steps)
+        ctx.set("profile", 1)
+        for _ in range(steps):
+            res.solve(stream)
+        torch.cuda.synchronize()
+        kern = read_kernel_ms(ctx)
+        ctx.set("profile", 0)
+        H = res.H.cpu().numpy().reshape(res.rows, res.cols, 3, 3)
+        d = rmse_delta(H[::8], H_default[::8], pair.src[:128])
+        a32, b32 = H.view(np.int32).astype(np.int64), H_default.view(np.int32).astype(np.int64)
+        flops = K1_FLOPS_PER_CELL_POINT * res.n * res.cells
+        out[tag] = {"value": res.cells * steps / t, "unit": "homographies/s", "solve_ms_per_step": t / steps * 1e3,
+                    "kernels_ms": {k: kern.get(k) for k in ("assemble", "eigen")},
+                    "k1_vs_default": kern["assemble"] / k1_default_ms,
+                    "roofline": {"kernel": "k_assemble_mfma<24 sums>", "bound": "mfma", "achieved": flops / (kern["assemble"] * 1e-3) / 1e12,
+                                 "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": flops / (kern["assemble"] * 1e-3) / 1e12 / PEAK_FP64_TFLOPS,
+                                 "note": "the same algorithmic 58 flops per (cell, keypoint) as the default's roofline"},
+                    "vs_default_grid": {"float32_values_differing": int((H != H_default).sum()), "of": int(H.size),
+                                        "max_ulp": int(np.abs(a32 - b32).max()), "rmse_delta_max_px": float(d.max()),
+                                        "rmse_delta_rows": "every 8th mesh row, 128 keypoints"}}
+        assert np.isfinite(H).all() and d.max() < 1e-4, f"opt-in mode {tag} outside north_star's bar"
+        del res
+        ctx.close()
     return out
 
 
@@ -634,6 +730,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cells", action="store_true", help="skip the `cells` (strong-scaling) object")
     ap.add_argument("--no-call-level", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` (C1, C2) and `moments24` objects")
     ap.add_argument("--no-c5", action="store_true", help="skip the `pairs` object (BASELINE config 5: 64 pairs over the ranks)")
     ap.add_argument("--c5-pairs", type=int, default=64)
     ap.add_argument("--c5-chunks", type=int, default=4, help="groups the rank's pairs are split into for the overlapped whole job")
@@ -888,6 +985,15 @@ def main():
         from_idle.append(time.perf_counter() - t0)
     t_idle = sorted(from_idle)[1]
 
+    # ------------------------------------------------------------------ BASELINE's other 1-GPU configurations, the opt-in solve forms
+    configs_obj = modes_obj = None
+    if world == 1 and not a.no_configs:
+        phase("configs C1, C2; opt-in solve forms")
+        configs_obj = {c: small_config(c, dev, stream, a.steps, timed, condition, back_to_back) for c in ("C1", "C2") if c != a.config}
+        if a.batch == 1 and a.variant == "auto":
+            H_default = res.H.cpu().numpy().reshape(res.rows, res.cols, 3, 3)
+            modes_obj = opt_in_modes(a.config, pair, dev, stream, a.steps, timed, condition, H_default, kern["assemble"])
+
     # ------------------------------------------------------------------ pairs as BASELINE config 5 states them
     c5_obj = None
     if not a.no_c5:
@@ -1126,6 +1232,8 @@ def main():
                                            "step alone leaves the chip partly idle (a set-up kernel of one wave per SIMD, then 1.45 "
                                            "generations of waves that compute together and wait together); a second, independent one "
                                            "fills it.  What a caller with several pairs in flight gets; extra, not `warp.value`"},
+            "configs": configs_obj,
+            "moments24": modes_obj,
             "pairs": c5_obj,
             "pair_per_rank": per_rank_obj,
             "cells": cells_obj,
@@ -1167,7 +1275,11 @@ def main():
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": warp_bytes / (k3_warm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "kernel_ms": k3_warm_ms, "kernel_ms_with_an_event_pair_per_launch": kern["warp"],
                 "timing": "HIP events on the launch stream around a run of launches issued back to back (duration + launch gap)",
-                "traffic": traffic_warp,
+                "traffic": traffic_warp, "traffic_raw": tj.get(f"{a.config}:k_warp_fast:raw"),
+                "traffic_note": "traffic_raw = FETCH_SIZE + WRITE_SIZE as the counters read (profiles/pmc_traffic.json); traffic = "
+                                "1.54 x FETCH_SIZE + WRITE_SIZE, the factor CHOSEN so that a cold launch's fetch equals the 24.9 MB "
+                                "image it must read (the counter does not count dword gathers in full): equal to the algorithmic "
+                                "bytes by construction, not a measurement of them.  Either way: no wasted traffic",
                 "note": "the bench warps the same 25 MB image into the same 27 MB canvas back to back: both stay in the "
                         "256 MiB Infinity Cache, so this figure is priced against a memory the kernel mostly does not "
                         "touch; roofline_warp_cold is the HBM one"},
@@ -1185,7 +1297,7 @@ def main():
                 "achieved": warp_bytes / (k3_cold_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": warp_bytes / (k3_cold_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "kernel_ms": k3_cold_ms,
                 "kernel_ms_with_an_event_pair_per_launch": kern_cold["warp"],
-                "traffic": tj.get(f"{a.config}:k_warp_fast:cold"),
+                "traffic": tj.get(f"{a.config}:k_warp_fast:cold"), "traffic_raw": tj.get(f"{a.config}:k_warp_fast:raw"),
                 "note": f"{len(cold)} (image, canvas) sets = {len(cold) * (res.img.numel() + res.out.numel()) / 1e6:.0f} MB "
                         f"warped in rotation: every launch reads its source from HBM and writes a canvas that is not cached"}
         if world == 1 and not a.no_call_level:

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("APAP_HIP_LIB") or os.path.join(_HERE, "libapap_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_INDEX, ERR_WORKSPACE = range(7)
-ABI_VERSION = 5          # APAP_ABI_VERSION of include/apap_hip.h
+ABI_VERSION = 6          # APAP_ABI_VERSION of include/apap_hip.h
 # kernel slots of apap_ctx_profile_read (include/apap_hip.h)
 PROF_NAMES = ("assemble", "eigen", "invert", "lut", "warp", "eq_hist", "eq_apply", "ransac")
 PROF_SLOTS = len(PROF_NAMES)
@@ -28,7 +28,7 @@ VARIANT_AUTO, VARIANT_VALU, VARIANT_MFMA, VARIANT_MFMA4, VARIANT_MFMA4X2 = 0, 1,
 EIGEN_AUTO, EIGEN_JACOBI, EIGEN_INVERSE_ITERATION = 0, 1, 2
 # options of a context (include/apap_hip.h)
 OPT_SOLVER_VARIANT, OPT_EIGEN_SOLVER, OPT_CAREFUL, OPT_PROFILE, OPT_WANT_WAVES, OPT_WARP_ROWS, OPT_WEIGHT_CHUNK_KB, \
-    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS = range(11)
+    OPT_FUSED_MAX_CELLS, OPT_WARP_FAST, OPT_OVERLAP_PCIE, OPT_PLAN_CELLS, OPT_MOMENTS, OPT_WEIGHTS_F32 = range(13)
 
 
 class ApapError(RuntimeError):
@@ -84,6 +84,7 @@ SIGNATURES = {
     "apap_host_dlt_rows_pts": (C.c_int, [_f64p, _f64p, C.c_int, C.c_int, _f32p]),
     "apap_host_build_table_rows": (C.c_int, [_f64p, _f32p, C.c_int, _f64p]),
     "apap_host_build_table": (C.c_int, [_f32p, _f32p, _f32p, C.c_int, _f64p]),
+    "apap_host_build_table24": (C.c_int, [_f64p, _f32p, C.c_int, _f64p]),
     "apap_host_build_denorm": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f64p]),
     "apap_local_homography": (C.c_int, [_vp, _f32p, _f32p, C.c_int, _f64p, C.c_int, C.c_int, C.c_double,
                                         C.c_double, _f32p, _f64p, C.c_int]),
@@ -194,7 +195,7 @@ class Context:
     _NAMES = {"variant": OPT_SOLVER_VARIANT, "eigen": OPT_EIGEN_SOLVER, "careful": OPT_CAREFUL, "profile": OPT_PROFILE,
               "want_waves": OPT_WANT_WAVES, "warp_rows": OPT_WARP_ROWS, "weight_chunk_kb": OPT_WEIGHT_CHUNK_KB,
               "fused_max_cells": OPT_FUSED_MAX_CELLS, "warp_fast": OPT_WARP_FAST, "overlap_pcie": OPT_OVERLAP_PCIE,
-              "plan_cells": OPT_PLAN_CELLS}
+              "plan_cells": OPT_PLAN_CELLS, "moments": OPT_MOMENTS, "weights_f32": OPT_WEIGHTS_F32}
 
     def set(self, name, value):
         check(lib().apap_ctx_set_option(self._h, self._NAMES[name], int(value)))
@@ -314,19 +315,25 @@ def _out_f64(out, shape):
     return out
 
 
-def host_build_table(src, cf1, cf2, out=None):
+def host_build_table(src, cf1, cf2, out=None, moments=30):
+    """The device keypoint table of ``apap_solve_device`` and its batch forms.  ``moments`` = 30 (default): the 30 distinct
+    entries of ``r1 r1^T + r2 r2^T`` of the reference's float32 DLT rows; 24: the exact-product table of a context with
+    ``moments=24`` (``apap_host_build_table24``; pass ``ctx.get("moments")``)."""
     src, s64 = as_points(src)
     cf1, a64 = as_points(cf1)
     cf2, b64 = as_points(cf2)
     n = src.shape[0]
     table = _out_f64(out, (n, TABLE_STRIDE))
-    if not (s64 or a64 or b64):
+    if moments not in (24, 30):
+        raise ValueError(f"moments must be 30 or 24, got {moments}")
+    if moments == 30 and not (s64 or a64 or b64):
         check(lib().apap_host_build_table(_ptr(src, C.c_float), _ptr(cf1, C.c_float), _ptr(cf2, C.c_float), n,
                                           _ptr(table, C.c_double)))
     else:       # from the DLT rows themselves and the source keypoints as float64
         aa = host_dlt_rows(cf1, cf2)
         src = np.ascontiguousarray(src, np.float64)
-        check(lib().apap_host_build_table_rows(_ptr(src, C.c_double), _ptr(aa, C.c_float), n, _ptr(table, C.c_double)))
+        build = lib().apap_host_build_table24 if moments == 24 else lib().apap_host_build_table_rows
+        check(build(_ptr(src, C.c_double), _ptr(aa, C.c_float), n, _ptr(table, C.c_double)))
     return table
 
 

@@ -8,7 +8,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
-#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -201,7 +200,9 @@ int apap_local_homography_pts(apap_ctx *ctx, const void *src, int src_f64, const
     for (size_t i = 0; i < (size_t)2 * n; ++i) src64[i] = src_f64 ? ((const double *)src)[i] : (double)((const float *)src)[i];
     std::vector<double> table((size_t)n * APAP_TABLE_STRIDE);
     double denorm[APAP_DENORM_DOUBLES];
-    if ((rc = apap_host_build_table_rows(src64.data(), aa.data(), n, table.data()))) return rc;
+    rc = apap::opt(ctx, APAP_OPT_MOMENTS) == 24 ? apap_host_build_table24(src64.data(), aa.data(), n, table.data())
+                                                : apap_host_build_table_rows(src64.data(), aa.data(), n, table.data());
+    if (rc) return rc;
     if ((rc = apap_host_build_denorm(iC2, C1, iN2, N1, denorm))) return rc;
     const SyncOnExit drain;   // the async copies below read `table` and `denorm`
 
@@ -230,7 +231,7 @@ int apap_local_homography_pts(apap_ctx *ctx, const void *src, int src_f64, const
 // ~1.1 ms, almost all of it PCIe one way at a time.  Here the caller's buffers are pinned for the call, the
 // source image goes up in row chunks on one stream, the canvas is warped in row bands on a second - band b
 // as soon as the source rows it can read have landed - and every finished band goes down on a third while
-// later chunks are still going up.  Measured on the MI355X boxes of this pool (APAP_TRACE_PIPE build, 4K pair):
+// later chunks are still going up.  Measured on the MI355X boxes of this pool (a build with host and event time stamps - git tag r05-hooks -, 4K pair):
 // 0.93 ms against 1.14 ms - the two directions do NOT add up here: 25 MB up alone and 27 MB down alone each move
 // at ~56 GB/s, both together at ~60 GB/s in all (the same with the canvas written straight into the pinned host
 // buffer by the kernel instead of a DMA copy), so what the overlap hides is the kernels, the set-up and the
@@ -287,11 +288,7 @@ int pipe_prepare(apap_ctx *pool, int dev, size_t n_events, size_t pinned_bytes) 
         }
     while (pool->events.size() < n_events) {
         hipEvent_t e;
-#ifdef APAP_TRACE_PIPE
-        APAP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDefault));       // the diagnostic build prints the device's own timeline
-#else
         APAP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-#endif
         pool->events.push_back(e);
     }
     if (pool->pinned_cap < pinned_bytes) {
@@ -322,14 +319,6 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
                     int n_w, const double *mesh_h, int n_h, int final_w, int final_h, int off_x, int off_y, uint8_t *out,
                     float *Hinv_out, const char *who, bool *done) {
     *done = false;
-#ifdef APAP_TRACE_PIPE      // diagnostic build: host-side timeline of the call on stderr
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto stamp = [&](const char *what) {
-        fprintf(stderr, "[pipe] %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
-    };
-#else
-    auto stamp = [](const char *) {};
-#endif
     const size_t img_bytes = (size_t)img_h * img_w * 3, out_bytes = (size_t)final_w * final_h * 3;
     const size_t cbytes = center ? (size_t)center_h * center_w * 3 : 0;
     if (img_bytes + out_bytes < (8u << 20)) return APAP_OK;      // small pairs: one copy each way is as good
@@ -362,7 +351,6 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     PinGuard pin_img, pin_out, pin_center;
     if (!pin_img.pin(img, img_bytes) || !pin_out.pin(out, out_bytes) || (center && !pin_center.pin(center, cbytes))) return APAP_OK;
 
-    stamp("pinned");
     const size_t work_bytes = apap_warp_workspace_bytes(mesh_rows, mesh_cols, final_w, final_h);
     void *d_H, *d_mw, *d_mh, *d_work, *d_status, *d_hinv = nullptr, *d_img, *d_out, *d_center = nullptr;
     if ((rc = slot_get(pool, S_H, (size_t)cells * 9 * sizeof(float), dev, &d_H))) return rc;
@@ -378,10 +366,6 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     hipStream_t s_up = (hipStream_t)pool->streams[0], s_k = (hipStream_t)pool->streams[1], s_dn = (hipStream_t)pool->streams[2];
     hipEvent_t *ev = reinterpret_cast<hipEvent_t *>(pool->events.data());
     hipEvent_t *e_img = ev, *e_cen = ev + chunks, *e_band = ev + 2 * chunks, e_setup = ev[2 * chunks + bands];
-#ifdef APAP_TRACE_PIPE
-    hipEvent_t *e_down = ev + 2 * chunks + bands + 2, e_start = ev[2 * chunks + bands + 1];
-    APAP_HIP_TRY(hipEventRecord(e_start, s_up));
-#endif
     int *h_rng = (int *)pool->pinned;
     int status = 0;
     const DrainStreams drain{pool};     // declared after everything the streams read or write
@@ -402,7 +386,6 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     };
     if ((rc = enqueue_uploads())) return rc;
 
-    stamp("uploads enqueued");
     // kernels stream: grid and edges up, set-up kernel, its source-row intervals back
     int *d_src_rows = nullptr;
     APAP_HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), s_k));
@@ -440,9 +423,7 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
         APAP_HIP_TRY(hipMemcpyAsync(Hinv_out, d_hinv, (size_t)cells * 9 * sizeof(float), hipMemcpyDeviceToHost, s_k));
 
     // the intervals: which chunk must have landed before band b may run
-    stamp("set-up enqueued");
     APAP_HIP_TRY(hipEventSynchronize(e_setup));
-    stamp("set-up done");
     // (the host's cell_row_of below is a binary search: valid on increasing edges only; the device's running-maximum table also
     // serves merely swapped edges, whose pixels all sit in ordinary cells and do not set the flag bit)
     const bool irregular = (h_rng[2 * mesh_rows] & 1) != 0 || !std::is_sorted(mesh_h, mesh_h + n_h);
@@ -484,34 +465,12 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
         APAP_HIP_TRY(hipEventRecord(e_band[b], s_k));
         APAP_HIP_TRY(hipStreamWaitEvent(s_dn, e_band[b], 0));
         APAP_HIP_TRY(hipMemcpyAsync(out + (size_t)y0 * final_w * 3, d_band, (size_t)(y1 - y0) * final_w * 3, hipMemcpyDeviceToHost, s_dn));
-#ifdef APAP_TRACE_PIPE
-        APAP_HIP_TRY(hipEventRecord(e_down[b], s_dn));
-#endif
     }
-    stamp("bands enqueued");
     APAP_HIP_TRY(hipMemcpyAsync(h_rng, d_status, sizeof(int), hipMemcpyDeviceToHost, s_k));
     APAP_HIP_TRY(hipStreamSynchronize(s_k));
-    stamp("kernels done");
     status = h_rng[0];
     APAP_HIP_TRY(hipStreamSynchronize(s_dn));
-    stamp("downloads done");
     APAP_HIP_TRY(hipStreamSynchronize(s_up));
-#ifdef APAP_TRACE_PIPE
-    {
-        auto at = [&](hipEvent_t e) {
-            float ms = -1.f;
-            if (hipEventElapsedTime(&ms, e_start, e) != hipSuccess) (void)hipGetLastError();
-            return ms * 1e3f;
-        };
-        fprintf(stderr, "[pipe] device: set-up done %.0f | chunk landed", at(e_setup));
-        for (int c = 0; c < chunks; ++c) fprintf(stderr, " %.0f", at(e_img[c]));
-        fprintf(stderr, " | band warped");
-        for (int b = 0; b < bands; ++b) fprintf(stderr, " %.0f", at(e_band[b]));
-        fprintf(stderr, " | band down");
-        for (int b = 0; b < bands; ++b) fprintf(stderr, " %.0f", at(e_down[b]));
-        fprintf(stderr, " us\n");
-    }
-#endif
     *done = true;
     return status_to_code(status, who);
 }

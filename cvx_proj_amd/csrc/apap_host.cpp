@@ -377,6 +377,33 @@ int apap_host_build_table_rows(const double *src, const float *aa, int n, double
     return APAP_OK;
 }
 
+int apap_host_build_table24(const double *src, const float *aa, int n, double *table) {
+    if (!src || !aa || !table || n < 1) return apap::fail(APAP_ERR_INVALID_ARG, "apap_host_build_table24: bad argument");
+    const long long marker_bits = 0x7ff8242424242424ll;     // kTable24Marker of apap_kernels.hip
+    double marker;
+    std::memcpy(&marker, &marker_bits, sizeof marker);
+    for (int k = 0; k < n; ++k) {
+        const float *r1 = aa + (size_t)18 * k, *r2 = r1 + 9;
+        const double x = r1[0], y = r1[1], c = r1[8], f = r2[8];
+        const double pp[6] = {x * x, x * y, x, y * y, y, 1.0};
+        const double r = c * c + f * f;
+        double *t = table + (size_t)APAP_TABLE_STRIDE * k;
+        for (int j = 0; j < 6; ++j) {
+            t[j] = pp[j];
+            t[6 + j] = c * pp[j];
+            t[12 + j] = f * pp[j];
+            t[18 + j] = r * pp[j];
+        }
+        t[24] = r1[6]; t[25] = r1[7]; t[26] = r2[6]; t[27] = r2[7];
+        t[28] = marker;
+        const float sf[2] = {(float)src[2 * k], (float)src[2 * k + 1]};
+        std::memcpy(&t[29], sf, sizeof(double));
+        t[30] = src[2 * k];
+        t[31] = src[2 * k + 1];
+    }
+    return APAP_OK;
+}
+
 int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, const float *N1,
                            double *denorm) {
     if (!iC2 || !C1 || !iN2 || !N1 || !denorm)

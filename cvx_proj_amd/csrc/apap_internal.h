@@ -27,7 +27,7 @@ enum { S_TABLE, S_VERT, S_DENORM, S_H, S_WORK, S_W, S_IMG, S_OUT, S_MESHW, S_MES
 // The context of include/apap_hip.h: options, profiling events, device-buffer pool.  Nothing else
 // in the library is mutable after load.
 struct apap_ctx {
-    int opt[APAP_OPT_COUNT] = {APAP_VARIANT_AUTO, APAP_EIGEN_AUTO, 1, 0, 4096, 1, 1 << 20, 4096, 1, 0, 0};
+    int opt[APAP_OPT_COUNT] = {APAP_VARIANT_AUTO, APAP_EIGEN_AUTO, 1, 0, 4096, 1, 1 << 20, 4096, 1, 0, 0, 30, 0};
     std::vector<apap::ProfSpan> spans;
     apap::DevSlot slots[apap::S_COUNT];
     std::mutex mu;   // serialises the host-buffer entry points that share this context's pool
@@ -78,7 +78,7 @@ struct SolvePlan {
     int pts_per_split; // keypoints per slice (a multiple of 4)
     size_t moment_bytes;
 };
-SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, int plan_cells = 0);
+SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, int plan_cells = 0, int moments = 30);
 
 // ---- the warp in two phases on one workspace (the host-buffer entry points overlap PCIe with it) ----
 constexpr int kWarpSetup = APAP_WARP_GEOMETRY | APAP_WARP_CELLS;   // lookup tables + cell inverses and fast records (and, if asked, source-row intervals)

@@ -19,23 +19,6 @@
 
 #include "apap_internal.h"
 
-#ifdef APAP_K3_TRACE     // diagnostic build (tools/k3_trace.py): per-wave time stamps inside k_warp_fast<false, 4>
-__device__ long long g_k3[16384 * 8];
-#define APAP_K3_STAMP(i)                                                                              \
-    do {                                                                                              \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
-        if (k3_id < 16384u && lane == 0) g_k3[k3_id * 8 + (i)] = (long long)wall_clock64();           \
-    } while (0)
-extern "C" int apap_debug_k3_trace(long long *out, int count) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3), sizeof(long long) * (size_t)count);
-}
-#else
-#define APAP_K3_STAMP(i) do { } while (0)
-#endif
-#ifdef APAP_TRACE_SMALL
-__device__ long long g_tq[16];
-#define APAP_STAMP(i) do { if (blockIdx.x == 3 && threadIdx.x == 0) g_tq[i] = clock64(); } while (0)
-#endif
 namespace {
 
 using apap::kMoments;
@@ -296,6 +279,24 @@ __device__ __forceinline__ double cell_weight_sq_tab(double vx, double vy, doubl
     return fmax(exp_neg_scaled(g * scaled_inv_sigma2, tab), gamma2);
 }
 
+// w^2 in float32 for the opt-in tolerance tier (APAP_OPT_WEIGHTS_F32 with APAP_OPT_MOMENTS = 24): v_sqrt_f32 and
+// v_exp_f32 (1 ulp each), 9 vector instructions instead of 24.  w^2 carries ~2e-7 relative error: the float32 grid moves by
+// at most one ulp in a few per cent of its entries (tools/moments24_study.py), like the 24-sum table itself.
+//   neg_scale = -2 log2(e) / sigma^2;  NaN coordinates give gamma^2 (v_max_f32 drops the NaN), as in the float64 chain
+__device__ __forceinline__ double cell_weight_sq_f32(float vx, float vy, float2 s, float neg_scale, float gamma2) {
+    const float dx = vx - s.x;
+    const float dy = vy - s.y;
+    const float d = __builtin_amdgcn_sqrtf(__builtin_fmaf(dx, dx, dy * dy));
+    return (double)fmaxf(__builtin_amdgcn_exp2f(d * neg_scale), gamma2);
+}
+
+// A 24-sum table (apap_host_build_table24) carries this quiet-NaN bit pattern in column 28 of every row; the kernels refuse
+// a table of the other layout (their grids come out NaN) instead of reading one layout as the other.
+constexpr long long kTable24Marker = 0x7ff8242424242424ll;
+__device__ __forceinline__ bool table_is_24(const double *__restrict__ table) {
+    return __double_as_longlong(table[28]) == kTable24Marker;
+}
+
 // --------------------------------------------------------------------------------
 // K1 (VALU variant): lanes = cells, one wave per 64-cell tile and keypoint split (grid.y).
 // Per keypoint the 32 table doubles are wave-uniform: they arrive through the scalar
@@ -375,13 +376,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // Keypoints per LDS buffer (16 KiB).  32 / 48 / 64 measured the same (196-200 us at C3): the
 // kernel is bound by the fp64 pipe, not by barriers or occupancy (VGPR + AGPR = 102 -> 4 waves
 // per SIMD; forcing <= 96 registers for 5-6 waves per SIMD changed nothing either).
-#ifndef APAP_K1_CHUNK
-#define APAP_K1_CHUNK 64
-#endif
-#ifndef APAP_K1_GROUP
-#define APAP_K1_GROUP 8
-#endif
-constexpr int kChunk = APAP_K1_CHUNK;
+constexpr int kChunk = 64;
 static_assert(kChunk % 16 == 0 && kChunk % 4 == 0, "chunk must split evenly over 256 threads and 4-keypoint steps");
 
 // Byte offset of table entry (row r, column c) in an LDS chunk: 256-B rows; odd rows swap
@@ -389,7 +384,14 @@ static_assert(kChunk % 16 == 0 && kChunk % 4 == 0, "chunk must split evenly over
 // 0-15 -> row r, 16-31 -> row r+1) fall on disjoint halves of the 64 banks.
 __device__ __forceinline__ int lds_off(int r, int c) { return r * 256 + ((c ^ ((r & 1) << 4)) << 3); }
 
-template <int kWaves>
+//
+// kM24 (APAP_OPT_MOMENTS = 24, opt-in): the table holds the 24 sums of the exact products (SURVEY.md section 8a:
+// A^T W^2 A = [[S0, 0, Sx], [0, S0, Sy], [Sx, Sy, Sr]], 6 unique entries each) in columns 0..23; per step ONE
+// v_mfma_f64_16x16x4_f64 covers columns 0..15 and TWO v_mfma_f64_4x4x4_4b_f64 columns 16..19 and 20..23, all three fed by
+// the same w^2 register: the two instruction forms share the lane -> (cell, keypoint) mapping of the A operand
+// (k_assemble_mfma4 below has the small form's layout).  Not bit-identical to the reference (its products are rounded to
+// float32, apap.py:103-119): one float32 ulp in a few per cent of the grid's entries.  kW32: weights by cell_weight_sq_f32.
+template <int kWaves, bool kM24, bool kW32>
 __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__restrict__ table, int n,
                                                        const double *__restrict__ vertices, int cells,
                                                        int cells_pad, double gamma2, double inv_sigma2,
@@ -418,6 +420,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
     const int cc = min(cell, cells - 1);
     const double vx = vertices[2 * cc];
     const double vy = vertices[2 * cc + 1];
+    const float vxf = (float)vx, vyf = (float)vy;
+    const float neg_scale_f = (float)(inv_sigma2 * -0x1.71547652b82fep+0), gamma2f = (float)gamma2;
     const int p_begin = min(n, (int)blockIdx.y * pts_per_split);
     const int p_end = min(n, p_begin + pts_per_split);
     const int nchunks = (p_end - p_begin + kChunk - 1) / kChunk;
@@ -446,8 +450,28 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         }
     };
 
-    const int off_xy = lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col), off_b1 = lds_off(kgrp, 16 + col);
+    const int off_xy = kW32 ? lds_off(kgrp, 29) : lds_off(kgrp, 30), off_b0 = lds_off(kgrp, col);
+    // second operand: columns 16..31 (30 sums), or columns 16 + (lane & 3) and, 32 bytes on, 20 + (lane & 3) (24 sums)
+    const int off_b1 = lds_off(kgrp, 16 + (kM24 ? (lane & 3) : col));
     double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    double acc_a = 0.0, acc_b = 0.0;
+    auto weight = [&](const unsigned char *at) -> double {
+        if constexpr (kW32) {
+            return cell_weight_sq_f32(vxf, vyf, *reinterpret_cast<const float2 *>(at), neg_scale_f, gamma2f);
+        } else {
+            const double2 xy = *reinterpret_cast<const double2 *>(at);
+            return cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+        }
+    };
+    auto accumulate = [&](double w2, const unsigned char *at0, const unsigned char *at1) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, *reinterpret_cast<const double *>(at0), acc0, 0, 0, 0);
+        if constexpr (kM24) {
+            acc_a = __builtin_amdgcn_mfma_f64_4x4x4f64(w2, *reinterpret_cast<const double *>(at1), acc_a, 0, 0, 0);
+            acc_b = __builtin_amdgcn_mfma_f64_4x4x4f64(w2, *reinterpret_cast<const double *>(at1 + 32), acc_b, 0, 0, 0);
+        } else {
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, *reinterpret_cast<const double *>(at1), acc1, 0, 0, 0);
+        }
+    };
     if (nchunks > 0) load_chunk(0);
 #pragma unroll
     for (int i = 0; i < kExpPerThread; ++i) s_exp2[(tid + i * kThreads) & (kExpN - 1)] = exp_stage[i];  // visible after the barrier
@@ -465,17 +489,10 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         // and 10 steps of the 16th - 2.3 % of the kernel).  Same MFMAs in the same order: identical sums.
         const int steps_here = min(kChunk / 4, (p_end - p_begin - c * kChunk + 3) >> 2);
         if (steps_here < kChunk / 4) {
-            for (int s1 = 0; s1 < steps_here; ++s1) {
-                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * s1);
-                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * s1);
-                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * s1);
-                const double w2 = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
-            }
+            for (int s1 = 0; s1 < steps_here; ++s1)
+                accumulate(weight(buf + off_xy + 1024 * s1), buf + off_b0 + 1024 * s1, buf + off_b1 + 1024 * s1);
             break;   // fewer than 64 keypoints left: this was the last chunk
         }
-#if APAP_K1_GROUP > 1
         // The weights of g steps first, then their 2 g MFMAs back to back: g times fewer MFMA <-> VALU
         // transitions (~10 issue cycles each, profiles/r02_coexec.txt) and g independent weight chains
         // for the scheduler.  Same MFMAs in the same order per accumulator: bit-identical sums.
@@ -483,43 +500,23 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         // 8: 163.8-164.1, 16: 163.9-164.2.  (s_setprio 1 / 3 around the MFMA group: +-1 %; a 128-keypoint
         // chunk: +4 %; profiles/r02_k1_variants.txt.)
 #pragma unroll
-        for (int s0 = 0; s0 < kChunk / 4; s0 += APAP_K1_GROUP) {
-            double w2[APAP_K1_GROUP];
+        for (int s0 = 0; s0 < kChunk / 4; s0 += 8) {
+            double w2[8];
 #pragma unroll
-            for (int g = 0; g < APAP_K1_GROUP; ++g) {
-                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * (s0 + g));
-                w2[g] = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
-            }
+            for (int g = 0; g < 8; ++g) w2[g] = weight(buf + off_xy + 1024 * (s0 + g));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int g = 0; g < APAP_K1_GROUP; ++g) {
-                const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * (s0 + g));
-                const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * (s0 + g));
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[g], b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[g], b1, acc1, 0, 0, 0);
-            }
+            for (int g = 0; g < 8; ++g) accumulate(w2[g], buf + off_b0 + 1024 * (s0 + g), buf + off_b1 + 1024 * (s0 + g));
             __builtin_amdgcn_sched_barrier(0);
         }
-#else
-#pragma unroll  // all 16 steps: LDS addresses become immediates (-3 % vs unroll 4)
-        for (int s = 0; s < kChunk / 4; ++s) {
-            // row 4 s + kgrp: its parity is kgrp's, so the swizzled offset is a per-lane base
-            // (hoisted out of the loop) plus the immediate 1024 s
-            const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * s);
-            const double b0 = *reinterpret_cast<const double *>(buf + off_b0 + 1024 * s);
-            const double b1 = *reinterpret_cast<const double *>(buf + off_b1 + 1024 * s);
-            const double w2 = cell_weight_sq_tab(vx, vy, xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
-        }
-#endif
         if (c + 1 < nchunks) store_chunk((c + 1) & 1);
         __syncthreads();
     }
 
     // D layout of v_mfma_f64_16x16x4_f64: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15],
     // row = cell within the wave's 16, col = moment index (acc0: 0..15, acc1: 16..31).
-    double *slab = moments + (size_t)blockIdx.y * kMoments * cells_pad;
+    constexpr int kSums = kM24 ? 24 : kMoments;
+    double *slab = moments + (size_t)blockIdx.y * kSums * cells_pad;
     const int cell_base = blockIdx.x * (16 * kWaves) + wave * 16 + kgrp;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -528,7 +525,15 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
             // (plain stores: non-temporal ones were measured - K1 150.0 -> 148.7 us, but the 128-byte pieces of a moment row no
             // longer merge in the L2 and WRITE_SIZE grows from 18.8 to 34.1 MB per launch, profiles/r05_solve_experiments.txt)
             slab[(size_t)col * cells_pad + ci] = acc0[i];
-            if (col < kMoments - 16) slab[(size_t)(16 + col) * cells_pad + ci] = acc1[i];
+            if (!kM24 && col < kMoments - 16) slab[(size_t)(16 + col) * cells_pad + ci] = acc1[i];
+        }
+    }
+    if constexpr (kM24) {
+        // D[b][i][j] of v_mfma_f64_4x4x4_4b_f64 sits in lane 16 i + 4 b + j: cell 4 b + i of the wave's 16, column 16 + j / 20 + j
+        const int ci = blockIdx.x * (16 * kWaves) + wave * 16 + 4 * ((lane >> 2) & 3) + (lane >> 4);
+        if (ci < cells_pad) {
+            slab[(size_t)(16 + (lane & 3)) * cells_pad + ci] = acc_a;
+            slab[(size_t)(20 + (lane & 3)) * cells_pad + ci] = acc_b;
         }
     }
 }
@@ -547,7 +552,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
 // kernel: every form ends at ~266 issue cycles per 64 (cell, keypoint) pairs = 128 for the
 // accumulation (32 x 4) + the weight chain.  The fp64 pipe is the bound, not the MFMA shape.
 // --------------------------------------------------------------------------------
-template <int kGroups>
+// kQuads = 8: the 32 columns of the 30-sum table; kQuads = 6: columns 0..23 of the 24-sum table (APAP_OPT_MOMENTS = 24, see
+// k_assemble_mfma); kW32: float32 weights (cell_weight_sq_f32).
+template <int kGroups, int kQuads, bool kW32>
 __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict__ table, int n,
                                                         const double *__restrict__ vertices, int cells,
                                                         int cells_pad, double gamma2, double inv_sigma2,
@@ -567,12 +574,16 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
     const int col = lane & 15;   // cell within a 16-cell group (A operand)
     const int cell0 = (blockIdx.x * 4 + wave) * (16 * kGroups);
     double vx[kGroups], vy[kGroups];
+    float vxf[kGroups], vyf[kGroups];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {
         const int cc = min(cell0 + 16 * g + col, cells - 1);
         vx[g] = vertices[2 * cc];
         vy[g] = vertices[2 * cc + 1];
+        vxf[g] = (float)vx[g];
+        vyf[g] = (float)vy[g];
     }
+    const float neg_scale_f = (float)(inv_sigma2 * -0x1.71547652b82fep+0), gamma2f = (float)gamma2;
     const int p_begin = min(n, (int)blockIdx.y * pts_per_split);
     const int p_end = min(n, p_begin + pts_per_split);
     const int nchunks = (p_end - p_begin + kChunk - 1) / kChunk;
@@ -598,15 +609,15 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
         }
     };
 
-    const int off_xy = lds_off(kgrp, 30);
+    const int off_xy = kW32 ? lds_off(kgrp, 29) : lds_off(kgrp, 30);
     // column 4 m + j of row kgrp: the swizzle only flips bit 4 of the column, so two per-lane bases
     // (columns 0-15 and 16-31) plus the immediate 32 (m & 3)
     const int off_lo = lds_off(kgrp, lane & 3), off_hi = lds_off(kgrp, 16 + (lane & 3));
-    double acc[kGroups][8];
+    double acc[kGroups][kQuads];
 #pragma unroll
     for (int g = 0; g < kGroups; ++g)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) acc[g][m] = 0.0;
+        for (int m = 0; m < kQuads; ++m) acc[g][m] = 0.0;
     if (nchunks > 0) {
         load_chunk(0);
         store_chunk(0);
@@ -618,17 +629,23 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
         const unsigned char *buf = lds[c & 1];
 #pragma unroll
         for (int s = 0; s < kChunk / 4; ++s) {
-            const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * s);
-            double bv[8];
+            double bv[kQuads];
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+            for (int m = 0; m < kQuads; ++m)
                 bv[m] = *reinterpret_cast<const double *>(buf + (m < 4 ? off_lo : off_hi) + 32 * (m & 3) + 1024 * s);
             double w2[kGroups];
+            if constexpr (kW32) {
+                const float2 xyf = *reinterpret_cast<const float2 *>(buf + off_xy + 1024 * s);
 #pragma unroll
-            for (int g = 0; g < kGroups; ++g)
-                w2[g] = cell_weight_sq_tab(vx[g], vy[g], xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+                for (int g = 0; g < kGroups; ++g) w2[g] = cell_weight_sq_f32(vxf[g], vyf[g], xyf, neg_scale_f, gamma2f);
+            } else {
+                const double2 xy = *reinterpret_cast<const double2 *>(buf + off_xy + 1024 * s);
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
+                for (int g = 0; g < kGroups; ++g)
+                    w2[g] = cell_weight_sq_tab(vx[g], vy[g], xy.x, xy.y, scaled_inv_sigma2, gamma2, s_exp2);
+            }
+#pragma unroll
+            for (int m = 0; m < kQuads; ++m)
 #pragma unroll
                 for (int g = 0; g < kGroups; ++g)
                     acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(w2[g], bv[m], acc[g][m], 0, 0, 0);
@@ -637,7 +654,8 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
         __syncthreads();
     }
     // D[b][i][j] sits in lane 16 i + 4 b + j: cell 4 b + i of the group, table column 4 m + j
-    double *slab = moments + (size_t)blockIdx.y * kMoments * cells_pad;
+    constexpr int kSums = kQuads == 6 ? 24 : kMoments;
+    double *slab = moments + (size_t)blockIdx.y * kSums * cells_pad;
     const int dcell = 4 * ((lane >> 2) & 3) + (lane >> 4);
     const int dj = lane & 3;
 #pragma unroll
@@ -645,8 +663,8 @@ __global__ __launch_bounds__(256) void k_assemble_mfma4(const double *__restrict
         const int ci = cell0 + 16 * g + dcell;
         if (ci < cells_pad) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-                if (4 * m + dj < kMoments) slab[(size_t)(4 * m + dj) * cells_pad + ci] = acc[g][m];
+            for (int m = 0; m < kQuads; ++m)
+                if (4 * m + dj < kSums) slab[(size_t)(4 * m + dj) * cells_pad + ci] = acc[g][m];
         }
     }
 }
@@ -852,10 +870,6 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
             }
         }
     }
-#ifdef APAP_TRACE_SMALL
-    APAP_STAMP(8);
-    int its = 0;
-#endif
     double v[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) v[k] = 1.0 / 3.0;
@@ -902,18 +916,11 @@ __device__ __forceinline__ bool inverse_iteration(const double (&a)[45], double 
             if (it >= 2) change = fmax(change, fabs(yn - v[i]));
             v[i] = yn;
         }
-#ifdef APAP_TRACE_SMALL
-        ++its;
-#endif
         if (it >= 2) {
             done = change <= 1e-14;  // false for NaN; the error left is that times lambda_9 / lambda_8
             if (__all(done || !ok)) break;
         }
     }
-#ifdef APAP_TRACE_SMALL
-    APAP_STAMP(9);
-    if (blockIdx.x == 3 && threadIdx.x == 0) g_tq[15] = its;
-#endif
 #pragma unroll
     for (int k = 0; k < 9; ++k) h[k] = v[k];
     rho = rcp_full(vMv);
@@ -1038,8 +1045,10 @@ __device__ __forceinline__ bool hestenes_rotate(double (&G)[81], double tol) {
 // float32 rounding, and within 3e-5 px of numpy's float64 SVD (whose own error that is).
 constexpr int kMaxHestenesSweeps = 30;
 
+// `m24`: the rows come from a 24-sum table (apap_host_build_table24: x'x, x'y, y'x, y'y as float32 products in columns
+// 24..27, -x' and -y' in columns 11 and 17).
 __device__ __forceinline__ void qr_resolve(const double *__restrict__ table, int n, double vx, double vy,
-                                        double inv_sigma, double gamma, int pick_rank, double (&h)[9]) {
+                                        double inv_sigma, double gamma, int pick_rank, bool m24, double (&h)[9]) {
     double R[45];
 #pragma unroll
     for (int k = 0; k < 45; ++k) R[k] = 0.0;
@@ -1049,12 +1058,12 @@ __device__ __forceinline__ void qr_resolve(const double *__restrict__ table, int
         const double x = row[2], y = row[4];
         double r[9];
         r[0] = w * x; r[1] = w * y; r[2] = w; r[3] = 0.0; r[4] = 0.0; r[5] = 0.0;
-        r[6] = w * row[12]; r[7] = w * row[13]; r[8] = w * row[14];
+        r[6] = w * row[m24 ? 24 : 12]; r[7] = w * row[m24 ? 25 : 13]; r[8] = w * row[m24 ? 11 : 14];
         givens_insert<0>(R, r); givens_insert<1>(R, r); givens_insert<2>(R, r);
         givens_insert<3>(R, r); givens_insert<4>(R, r); givens_insert<5>(R, r);
         givens_insert<6>(R, r); givens_insert<7>(R, r); givens_insert<8>(R, r);
         r[0] = 0.0; r[1] = 0.0; r[2] = 0.0; r[3] = w * x; r[4] = w * y; r[5] = w;
-        r[6] = w * row[21]; r[7] = w * row[22]; r[8] = w * row[23];
+        r[6] = w * row[m24 ? 26 : 21]; r[7] = w * row[m24 ? 27 : 22]; r[8] = w * row[m24 ? 17 : 23];
         givens_insert<3>(R, r); givens_insert<4>(R, r); givens_insert<5>(R, r);
         givens_insert<6>(R, r); givens_insert<7>(R, r); givens_insert<8>(R, r);
     }
@@ -1149,7 +1158,7 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
                                                   int pick_rank, int careful, const double *__restrict__ table, int n,
                                                   double vx, double vy, double gamma, double inv_sigma,
                                                   float *__restrict__ out /* 9 floats, or nullptr */,
-                                                  const WarpEmit &we, int pair, int cell, const CellEdges &edges) {
+                                                  const WarpEmit &we, int pair, int cell, const CellEdges &edges, bool m24 = false) {
     // A^T W^2 A = [[S0, 0, S1], [0, S0, S2], [S1^T, S2^T, S3]]  (3x3 blocks)
     double a[45];
 #pragma unroll
@@ -1167,9 +1176,6 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
         }
     a[tri(6, 6)] = m[24]; a[tri(6, 7)] = m[25]; a[tri(6, 8)] = m[26];
     a[tri(7, 7)] = m[27]; a[tri(7, 8)] = m[28]; a[tri(8, 8)] = m[29];
-#ifdef APAP_TRACE_SMALL
-    APAP_STAMP(0);
-#endif
     const double trace = 2.0 * (m[0] + m[3] + m[5]) + m[24] + m[27] + m[29];
     const double gap_tol = kGapTol * trace;
     // The sums are of w^2: where every weight is below ~1e-140 they underflow (partly or entirely)
@@ -1186,15 +1192,9 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
         double rho;
         int below;
         have = inverse_iteration(a, h, rho, m, gap_tol, below);
-#ifdef APAP_TRACE_SMALL
-        APAP_STAMP(1);
-#endif
         // a second eigenvalue within gap_tol of the smallest?  (rho >= lambda_9, so lambda_9 counts)
         if (careful && !careful_cell) careful_cell = have && below >= 2;
     }
-#ifdef APAP_TRACE_SMALL
-    APAP_STAMP(2);
-#endif
     if (!__all(have || careful_cell)) {  // rare: no spectral gap, pivot not positive (n < 5 with careful == 0)
         double hj[9];
         const double gap = jacobi_eigvec(a, pick_rank, hj);
@@ -1204,13 +1204,10 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
     }
     if (__any(careful_cell)) {
         double hq[9];
-        qr_resolve(table, n, vx, vy, inv_sigma, gamma, pick_rank, hq);
+        qr_resolve(table, n, vx, vy, inv_sigma, gamma, pick_rank, m24, hq);
 #pragma unroll
         for (int k = 0; k < 9; ++k) h[k] = careful_cell ? hq[k] : h[k];
     }
-#ifdef APAP_TRACE_SMALL
-    APAP_STAMP(3);
-#endif
     double t1[9], t2[9];
     mul3(denorm, h, t1);        // inv(C2) . h
     mul3(t1, denorm + 9, t2);   // . C1
@@ -1241,20 +1238,13 @@ __device__ __forceinline__ void eigen_denorm_cell(const double (&m)[kMoments], c
         // warp's workspace (what k_warp_setup's per-cell half would compute from the stored grid: the same function)
         if (we.hinv_pad) warp_emit_from_solve(we, pair, cell, hf, edges);
     }
-#ifdef APAP_TRACE_SMALL
-    APAP_STAMP(4);
-    if (blockIdx.x == 3 && threadIdx.x == 0)
-        printf("  tail: build+factorise %lld  %lld solves %lld  guard %lld  votes %lld  denorm+store %lld\n", g_tq[8] - g_tq[0], g_tq[15],
-               g_tq[9] - g_tq[8], g_tq[2] - g_tq[1], g_tq[3] - g_tq[2], g_tq[4] - g_tq[3]);
-#endif
 }
 
 // K2.  kUseInverseIteration = false is the pure-Jacobi kernel (APAP_EIGEN_JACOBI).
-#ifndef APAP_K2_WAVES_ATTR
-#define APAP_K2_WAVES_ATTR
-#endif
-template <bool kUseInverseIteration>
-__global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const double *__restrict__ moments, int splits,
+// kM24: the slabs hold the 24 sums S0, Sx, Sy, Sr (6 each, upper triangle of a 3 x 3 by rows) of K1's 24-sum form; the 30
+// entries the tail works on are those with Sx and Sy written out as full 3 x 3 blocks.
+template <bool kUseInverseIteration, bool kM24>
+__global__ __launch_bounds__(64) void k_eigen_denorm(const double *__restrict__ moments, int splits,
                                                      int cells, int cells_pad,
                                                      const double *__restrict__ denorm, int pick_rank,
                                                      float *__restrict__ H, BatchStride bs,
@@ -1269,16 +1259,42 @@ __global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const do
     const int cell = blockIdx.x * kWave + threadIdx.x;
     const int cc = min(cell, cells - 1);
     const CellEdges edges = warp_emit_prefetch(we, cell < cells ? cell : -1);
-    double m[kMoments];
+    constexpr int kSums = kM24 ? 24 : kMoments;
+    const bool layout_ok = table_is_24(table) == kM24;   // (one scalar load, long before the tail needs it)
+    double t[kSums];
 #pragma unroll
-    for (int j = 0; j < kMoments; ++j) m[j] = moments[(size_t)j * cells_pad + cc];
+    for (int j = 0; j < kSums; ++j) t[j] = moments[(size_t)j * cells_pad + cc];
     for (int g = 1; g < splits; ++g) {  // slabs of the keypoint splits, fixed order
-        const double *slab = moments + (size_t)g * kMoments * cells_pad + cc;
+        const double *slab = moments + (size_t)g * kSums * cells_pad + cc;
 #pragma unroll
-        for (int j = 0; j < kMoments; ++j) m[j] += slab[(size_t)j * cells_pad];
+        for (int j = 0; j < kSums; ++j) t[j] += slab[(size_t)j * cells_pad];
     }
+    double m[kMoments];
+    if constexpr (kM24) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            m[j] = t[j];
+            m[24 + j] = t[18 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int u = i <= j ? i * (5 - i) / 2 + j : j * (5 - j) / 2 + i;   // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+                m[6 + 3 * i + j] = t[6 + u];
+                m[15 + 3 * i + j] = t[12 + u];
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kMoments; ++j) m[j] = t[j];
+    }
+    float *out = cell < cells ? H + (size_t)cell * 9 : nullptr;
     eigen_denorm_cell<kUseInverseIteration>(m, denorm, pick_rank, careful, table, n, vertices[2 * cc], vertices[2 * cc + 1],
-                                            gamma, inv_sigma, cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell, edges);
+                                            gamma, inv_sigma, out, we, (int)blockIdx.z, cell, edges, kM24);
+    if (!layout_ok && out) {      // the caller's table has the other layout (wave-uniform): nothing computed from it is an answer
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out[k] = __builtin_nanf("");
+    }
 }
 
 // --------------------------------------------------------------------------------
@@ -1290,10 +1306,7 @@ __global__ __launch_bounds__(64) APAP_K2_WAVES_ATTR void k_eigen_denorm(const do
 // as many blocks as K1 would start.  Register use is the K2 tail's (one wave per SIMD): fine for the
 // few dozen to few hundred blocks this kernel is dispatched for.
 // --------------------------------------------------------------------------------
-#ifndef APAP_SMALL_WAVES
-#define APAP_SMALL_WAVES 4
-#endif
-constexpr int kSmallWaves = APAP_SMALL_WAVES;       // waves of a fused block: they split every chunk's 16 steps
+constexpr int kSmallWaves = 4;       // waves of a fused block: they split every chunk's 16 steps
 constexpr int kSmallThreads = kSmallWaves * 64;
 static_assert(kSmallWaves == 4 || kSmallWaves == 8, "the chunk's 16 steps and the staging split evenly over 4 or 8 waves");
 template <bool kUseInverseIteration>
@@ -1313,10 +1326,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
     denorm += (long long)blockIdx.z * bs.denorm;
     H += (long long)blockIdx.z * bs.H;
     const int tid = threadIdx.x;
-#ifdef APAP_TRACE_SMALL
-    long long tr[6];
-    tr[0] = clock64();
-#endif
     constexpr int kExpPerThread = kExpN / kSmallThreads;
     double exp_stage[kExpPerThread];   // to LDS after the first round's loads are issued
 #pragma unroll
@@ -1370,9 +1379,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
     if (tid < APAP_DENORM_DOUBLES) s_denorm[tid] = den_stage;
     store_round();
     __syncthreads();
-#ifdef APAP_TRACE_SMALL
-    tr[1] = clock64();
-#endif
     for (int r = 0; r < nrounds; ++r) {
         if (r + 1 < nrounds) load_round(r + 1);
         const int live = min(kRing, nchunks - r * kRing);   // chunks of this round (block-uniform)
@@ -1423,9 +1429,6 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
     double *part = reinterpret_cast<double *>(&lds[0][0]);
     double *tot = part + kSmallWaves * 16 * kRow;
     static_assert((kSmallWaves + 1) * 16 * kRow * sizeof(double) <= sizeof(lds), "reduction buffers fit the chunk ring");
-#ifdef APAP_TRACE_SMALL
-    tr[2] = clock64();
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ci = kgrp + 4 * i;
@@ -1443,21 +1446,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_solve_small(const double *__r
     }
     __syncthreads();
     if (wave != 0 || lane >= 16) return;       // lanes 0..15 of wave 0 = the block's 16 cells
-#ifdef APAP_TRACE_SMALL
-    tr[3] = clock64();
-#endif
     double m[kMoments];
 #pragma unroll
     for (int j = 0; j < kMoments; ++j) m[j] = tot[lane * kRow + j];
     const CellEdges edges = warp_emit_prefetch(we, cell < cells ? cell : -1);
     eigen_denorm_cell<kUseInverseIteration>(m, s_denorm, pick_rank, careful, table, n, vx, vy, gamma, inv_sigma,
                                             cell < cells ? H + (size_t)cell * 9 : nullptr, we, (int)blockIdx.z, cell, edges);
-#ifdef APAP_TRACE_SMALL
-    tr[4] = clock64();
-    if (blockIdx.x == 3 && tid == 0)
-        printf("k_solve_small block 3: prologue %lld  loop %lld  reduce %lld  tail %lld cycles (s_memtime)\n", tr[1] - tr[0],
-               tr[2] - tr[1], tr[3] - tr[2], tr[4] - tr[3]);
-#endif
+    if (table_is_24(table) && cell < cells) {   // a 24-sum table: this kernel reads the 30-sum layout
+#pragma unroll
+        for (int k = 0; k < 9; ++k) H[(size_t)cell * 9 + k] = __builtin_nanf("");
+    }
 }
 
 // --------------------------------------------------------------------------------
@@ -2332,11 +2330,7 @@ __global__ __launch_bounds__(256) void k_warp_rows(const uint8_t *__restrict__ i
 __device__ __forceinline__ unsigned gather_px(const uint8_t *__restrict__ img, unsigned o, unsigned last) {
     unsigned int v;
     const unsigned oc = o < last ? o : last;
-#ifdef APAP_K3_ABL_NOGATHER
-    v = oc;
-#else
     __builtin_memcpy(&v, img + oc, 4);
-#endif
     v = __builtin_amdgcn_alignbyte(0u, v, o - oc);
     // v & 0xffffff & ~sign(o): v_bfe_i32 + v_bitop3_b32 (truth table a & b & ~c = 0x40)
     return (unsigned)__builtin_amdgcn_bitop3_b32((int)v, 0x00ffffff, __builtin_amdgcn_sbfe((int)o, 31u, 1u), 0x40);
@@ -2364,14 +2358,8 @@ __device__ __forceinline__ unsigned exact_offset(const double *__restrict__ hinv
     return ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
 }
 
-#ifndef APAP_K3_BUF
-#define APAP_K3_BUF 0
-#endif
-#ifndef APAP_K3_WAVES_ATTR
-#define APAP_K3_WAVES_ATTR
-#endif
 template <bool kBlend, int kRows>
-__global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
+__global__ __launch_bounds__(256) void k_warp_fast(const uint8_t *__restrict__ img, int img_h, int img_w,
                                                    const double *__restrict__ hinv_pad, int mesh_rows, int mesh_cols,
                                                    const int *__restrict__ lut, const float4 *__restrict__ frec,
                                                    const unsigned *__restrict__ fcol, const uint2 *__restrict__ frow,
@@ -2389,10 +2377,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
     }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef APAP_K3_TRACE
-    const unsigned k3_id = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (unsigned)wave;
-    APAP_K3_STAMP(0);
-#endif
     const int j0 = ((int)blockIdx.x * 64 + lane) * 4;
     const int y_first = row_begin + ((int)blockIdx.y * (int)(blockDim.x >> 6) + wave) * kRows;
     const int y_end = min(y_first + kRows, row_begin + row_count);
@@ -2418,11 +2402,7 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         rr[t] = __builtin_amdgcn_readfirstlane(e.x);
         dyf[t] = __uint_as_float(__builtin_amdgcn_readfirstlane(e.y));
     }
-#ifdef APAP_K3_ABL_NOSTAMP      // (A/B build: what the check costs)
-    const bool ready = true;
-#else
     const bool ready = (rr[0] >> 16) == warp_stamp16(mesh_rows, mesh_cols, final_w, final_h);
-#endif
     const unsigned cmask = ready ? 0xffffu : 0u;
     if (!ready && lane == 0) atomicOr(status, apap::kStatusUnprepared);
 #pragma unroll
@@ -2432,25 +2412,11 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         col[k] = cev[k] & cmask;
         dxf[k] = (float)((cev[k] >> 16) & 0xffu) - 128.0f;    // v_cvt_f32_ubyte2; the byte is biased by 128
     }
-    APAP_K3_STAMP(1);       // column and row entries have arrived
     unsigned off[kRows][4];
     unsigned int px[kRows][4];
     unsigned long long doubt[kRows][4];    // lane masks (scalar registers)
-#if APAP_K3_BUF
-    unsigned patch = 0u;                   // per lane: pixels that are the image's very last pixel
-#endif
     const unsigned rec_stride = (unsigned)(mesh_cols + 1);
     unsigned todo = (1u << kRows) - 1u;
-#ifdef APAP_K3_ABL_COPY   // experiment: no coordinate work at all - the access pattern's own floor
-    todo = 0u;
-#pragma unroll
-    for (int t = 0; t < kRows; ++t)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            doubt[t][k] = 0;
-            off[t][k] = (__umul24((unsigned)min(y_first + t, img_h - 1), (unsigned)img_w) + (unsigned)min(j0 + k, img_w - 1)) * 3u;
-        }
-#endif
     while (todo != 0u) {    // one pass per cell row the strip touches; wave-uniform
         const int first = __builtin_ctz(todo);
         unsigned r = rr[0];
@@ -2459,18 +2425,13 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         const unsigned base = r * rec_stride;
         const float4 *pa = frec + (size_t)(base + col[0]) * 3, *pb = frec + (size_t)(base + col[3]) * 3;
         const float4 a0 = pa[0], a1 = pa[1], a2 = pa[2], b0 = pb[0], b1 = pb[1], b2 = pb[2];
-        APAP_K3_STAMP(2);   // the records of this pass have arrived (the last pass's stamp stays)
         // per pixel: x-dependent parts of the three sums, the y coefficients, anchor, window
         float nx0[4], ny0[4], dn0[4], bx[4], by[4], h7[4];
         int n0x[4], n0y[4];
         unsigned thr[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-#ifdef APAP_K3_ABL_ONECELL     // experiment (wrong pixels where a lane straddles two cells): fewer registers -> more waves per SIMD?
-            const bool is_a = true;
-#else
             const bool is_a = (k == 0) || (k != 3 && col[k] == col[0]);
-#endif
             const float4 q0 = is_a ? a0 : b0, q1 = is_a ? a1 : b1, q2 = is_a ? a2 : b2;
             nx0[k] = __builtin_fmaf(q0.x, dxf[k], q0.z);
             ny0[k] = __builtin_fmaf(q0.w, dxf[k], q1.y);
@@ -2498,16 +2459,10 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
                 const unsigned lo = min((unsigned)fx & 0xffffu, (unsigned)fy & 0xffffu);
                 const bool ok = ((unsigned)ix < (unsigned)img_w) & ((unsigned)iy < (unsigned)img_h);
                 off[t][k] = ok ? (__umul24((unsigned)iy, (unsigned)img_w) + (unsigned)ix) * 3u : 0xffffffffu;
-#if APAP_K3_BUF
-                // the image's last pixel must not be fetched through the descriptor (its dword reaches one byte past the image)
-                doubt[t][k] = __builtin_amdgcn_ballot_w64((lo < thr[k]) | (off[t][k] == last + 1u));
-#else
                 doubt[t][k] = __builtin_amdgcn_ballot_w64(lo < thr[k]);
-#endif
             }
         }
     }
-    APAP_K3_STAMP(3);       // offsets computed
     // pixels in doubt: the exact float64 sequence.  Only waves that hold one come here.
     {
         unsigned long long any = 0;
@@ -2515,9 +2470,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
         for (int t = 0; t < kRows; ++t)
 #pragma unroll
             for (int k = 0; k < 4; ++k) any |= doubt[t][k];
-#ifdef APAP_K3_ABL_NODOUBT     // experiment (wrong pixels): what the exact path costs
-        any = 0;
-#endif
         if (any != 0) {
             unsigned bits = 0;
 #pragma unroll
@@ -2534,12 +2486,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
 #pragma unroll
                 for (int k = 1; k < 4; ++k) cc = (idx & 3) == k ? col[k] : cc;
                 unsigned o = exact_offset(hinv_pad, lut, mesh_rows, mesh_cols, final_h, cr, cc, i, j, off_x, off_y, img_w, img_h);
-#if APAP_K3_BUF
-                if (o == last + 1u) {
-                    patch |= 1u << idx;
-                    o = 0xffffffffu;
-                }
-#endif
 #pragma unroll
                 for (int t = 0; t < kRows; ++t)
 #pragma unroll
@@ -2551,32 +2497,10 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
     // the range tests and the last-pixel guard for waves wholly inside the source, measured no faster: DESIGN.md;
     // one 16-byte window load per lane and row with the gathers kept for the lanes it cannot serve, and two 12-byte
     // windows per lane and row for every lane: byte-identical and 13-26 % slower, profiles/r05_k3_experiments.txt 2b, 2c)
-#if APAP_K3_BUF
-    {
-        // source pixels through a buffer descriptor over the image: the range check returns 0 for the "outside" marker, so a
-        // gathered dword needs one AND instead of clamp / shift / sign mask
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img), (short)0, (int)(last + 4u), 0x00020000);
-#pragma unroll
-        for (int t = 0; t < kRows; ++t)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) px[t][k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off[t][k], 0, 0) & 0x00ffffffu;
-        if (__builtin_amdgcn_ballot_w64(patch != 0u) != 0) {     // the image's last pixel: the dword one byte earlier, shifted
-            unsigned last_px;
-            __builtin_memcpy(&last_px, img + last, 4);
-            last_px >>= 8;
-#pragma unroll
-            for (int t = 0; t < kRows; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) px[t][k] = ((patch >> (t * 4 + k)) & 1u) ? last_px : px[t][k];
-        }
-    }
-#else
 #pragma unroll
     for (int t = 0; t < kRows; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k) px[t][k] = gather_px(img, off[t][k], last);
-#endif
-    APAP_K3_STAMP(4);       // exact path done (if taken), gathers issued AND landed
     const int y_store_end = ready ? y_end : y_first;     // a foreign workspace: no row is stored
 #pragma unroll
     for (int t = 0; t < kRows; ++t) {
@@ -2599,9 +2523,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
             }
         }
         uint8_t *o = out + ((size_t)(y - row_begin) * (size_t)final_w) * 3 + (unsigned)j0 * 3u;
-#ifdef APAP_K3_ABL_NOSTORE
-        if ((px[t][0] ^ px[t][1] ^ px[t][2] ^ px[t][3]) != 0x12345678u) continue;   // never true for 24-bit pixels
-#endif
         if (npx == 4) {
             // 4 x 24 bits -> 3 dwords (v_perm_b32 picks bytes 0-3 from its second operand, 4-7 from its first), stored
             // NON-TEMPORAL: the canvas is written once and never read back by this kernel - the bytes stream past the L2
@@ -2618,7 +2539,6 @@ __global__ __launch_bounds__(256) APAP_K3_WAVES_ATTR void k_warp_fast(const uint
             }
         }
     }
-    APAP_K3_STAMP(5);       // stores issued and acknowledged
 }
 
 // coordinates only (parity tests of the arithmetic of k_warp)
@@ -2709,7 +2629,7 @@ ProfScope::~ProfScope() {
     ctx_->spans.push_back(ProfSpan{slot_, a_, b_});
 }
 
-SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, int plan_cells) {
+SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, int plan_cells, int moments) {
     SolvePlan p{};
     if (variant == APAP_VARIANT_AUTO) variant = APAP_VARIANT_MFMA;  // measured faster on C2-C4, DESIGN.md
     p.variant = variant;
@@ -2733,7 +2653,7 @@ SolvePlan plan_solve(int n, int cells, int variant, int batch, int want_waves, i
     pps = (pps + kChunk - 1) / kChunk * kChunk;
     p.splits = (n + pps - 1) / pps;  // no empty split
     p.pts_per_split = pps;
-    p.moment_bytes = (size_t)p.splits * kMoments * p.cells_pad * sizeof(double);
+    p.moment_bytes = (size_t)p.splits * (moments == 24 ? 24 : kMoments) * p.cells_pad * sizeof(double);
     return p;
 }
 
@@ -2772,7 +2692,9 @@ int apap_ctx_set_option(apap_ctx *ctx, int option, int value) {
         case APAP_OPT_FUSED_MAX_CELLS:
         case APAP_OPT_PLAN_CELLS: ok = value >= 0; break;
         case APAP_OPT_WARP_FAST:
-        case APAP_OPT_OVERLAP_PCIE: ok = value == 0 || value == 1; break;
+        case APAP_OPT_OVERLAP_PCIE:
+        case APAP_OPT_WEIGHTS_F32: ok = value == 0 || value == 1; break;
+        case APAP_OPT_MOMENTS: ok = value == 30 || value == 24; break;
         default: return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: unknown option %d", option);
     }
     if (!ok) return apap::fail(APAP_ERR_INVALID_ARG, "apap_ctx_set_option: value %d is not valid for option %d", value, option);
@@ -2809,7 +2731,8 @@ int apap_ctx_profile_read(apap_ctx *ctx, float *ms, int *launches) {
 
 size_t apap_solve_batch_workspace_bytes(apap_ctx *ctx, int n, int cells, int batch) {
     if (n < 1 || cells < 1 || batch < 1) return 0;
-    return apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES), apap::opt(ctx, APAP_OPT_PLAN_CELLS)).moment_bytes * (size_t)batch;
+    return apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES), apap::opt(ctx, APAP_OPT_PLAN_CELLS),
+                            apap::opt(ctx, APAP_OPT_MOMENTS)).moment_bytes * (size_t)batch;
 }
 
 size_t apap_solve_workspace_bytes(apap_ctx *ctx, int n, int cells) { return apap_solve_batch_workspace_bytes(ctx, n, cells, 1); }
@@ -2823,7 +2746,12 @@ static int solve_batch_impl(apap_ctx *ctx, const double *d_tables, int n, const 
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: null device pointer");
     if (n < 1 || cells < 1 || batch < 1 || batch > 65535 || vertices_stride < 0)
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: n=%d cells=%d batch=%d", n, cells, batch);
-    const apap::SolvePlan p = apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES), apap::opt(ctx, APAP_OPT_PLAN_CELLS));
+    const bool m24 = apap::opt(ctx, APAP_OPT_MOMENTS) == 24;
+    const bool w32 = m24 && apap::opt(ctx, APAP_OPT_WEIGHTS_F32) != 0;   // float32 weights exist in the 24-sum kernels only
+    if (m24 && apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_VALU)
+        return apap::fail(APAP_ERR_INVALID_ARG, "apap_solve_device: APAP_OPT_MOMENTS = 24 has no VALU form (use AUTO, MFMA, MFMA4 or MFMA4X2)");
+    const apap::SolvePlan p = apap::plan_solve(n, cells, apap::opt(ctx, APAP_OPT_SOLVER_VARIANT), batch, apap::opt(ctx, APAP_OPT_WANT_WAVES),
+                                               apap::opt(ctx, APAP_OPT_PLAN_CELLS), m24 ? 24 : 30);
     if (work_bytes < p.moment_bytes * (size_t)batch)
         return apap::fail(APAP_ERR_WORKSPACE, "apap_solve_device: workspace %zu < %zu bytes", work_bytes,
                           p.moment_bytes * (size_t)batch);
@@ -2843,7 +2771,7 @@ static int solve_batch_impl(apap_ctx *ctx, const double *d_tables, int n, const 
     // Small meshes (AUTO only): one fused launch, 16 cells per block.  Up to 4096 cells in all the
     // blocks fit the chip in about one round at the fused kernel's one wave per SIMD.
     const int plan_cells = apap::opt(ctx, APAP_OPT_PLAN_CELLS);
-    if (apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO &&
+    if (!m24 && apap::opt(ctx, APAP_OPT_SOLVER_VARIANT) == APAP_VARIANT_AUTO &&    // (the fused kernel reads the 30-sum table)
         (plan_cells > 0 ? (long long)plan_cells : (long long)cells * batch) <= apap::opt(ctx, APAP_OPT_FUSED_MAX_CELLS)) {
         ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);   // reported under the K1 slot; the K2 slot stays empty
         const dim3 grid((cells + 15) / 16, 1, batch);
@@ -2861,28 +2789,35 @@ static int solve_batch_impl(apap_ctx *ctx, const double *d_tables, int n, const 
         ProfScope prof(ctx, APAP_PROF_ASSEMBLE, s);
         const dim3 grid(p.cell_tiles, p.splits, batch);
         // 4 waves (64 cells) per block measured best: 2 -> 224 us, 4 -> 201 us, 8 -> 227 us at C3
-        if (p.variant == APAP_VARIANT_MFMA)
-            hipLaunchKernelGGL(k_assemble_mfma<4>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
-                               inv_sigma2, p.pts_per_split, moments, bs);
-        else if (p.variant == APAP_VARIANT_MFMA4)
-            hipLaunchKernelGGL(k_assemble_mfma4<1>, grid, dim3(256), 0, s, d_tables, n, d_vertices, cells, p.cells_pad, gamma2,
-                               inv_sigma2, p.pts_per_split, moments, bs);
-        else if (p.variant == APAP_VARIANT_MFMA4X2)
-            hipLaunchKernelGGL(k_assemble_mfma4<2>, dim3((p.cell_tiles + 1) / 2, p.splits, batch), dim3(256), 0, s, d_tables, n,
-                               d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
-        else
-            hipLaunchKernelGGL(k_assemble_valu, dim3((p.cell_tiles + 3) / 4, p.splits, batch), dim3(256), 0, s, d_tables, n,
-                               d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs);
+#define APAP_K1_ARGS d_tables, n, d_vertices, cells, p.cells_pad, gamma2, inv_sigma2, p.pts_per_split, moments, bs
+        const dim3 grid2((p.cell_tiles + 1) / 2, p.splits, batch);   // two 64-cell tiles per block
+        if (p.variant == APAP_VARIANT_MFMA) {
+            if (!m24) hipLaunchKernelGGL((k_assemble_mfma<4, false, false>), grid, dim3(256), 0, s, APAP_K1_ARGS);
+            else if (!w32) hipLaunchKernelGGL((k_assemble_mfma<4, true, false>), grid, dim3(256), 0, s, APAP_K1_ARGS);
+            else hipLaunchKernelGGL((k_assemble_mfma<4, true, true>), grid, dim3(256), 0, s, APAP_K1_ARGS);
+        } else if (p.variant == APAP_VARIANT_MFMA4) {
+            if (!m24) hipLaunchKernelGGL((k_assemble_mfma4<1, 8, false>), grid, dim3(256), 0, s, APAP_K1_ARGS);
+            else if (!w32) hipLaunchKernelGGL((k_assemble_mfma4<1, 6, false>), grid, dim3(256), 0, s, APAP_K1_ARGS);
+            else hipLaunchKernelGGL((k_assemble_mfma4<1, 6, true>), grid, dim3(256), 0, s, APAP_K1_ARGS);
+        } else if (p.variant == APAP_VARIANT_MFMA4X2) {
+            if (!m24) hipLaunchKernelGGL((k_assemble_mfma4<2, 8, false>), grid2, dim3(256), 0, s, APAP_K1_ARGS);
+            else if (!w32) hipLaunchKernelGGL((k_assemble_mfma4<2, 6, false>), grid2, dim3(256), 0, s, APAP_K1_ARGS);
+            else hipLaunchKernelGGL((k_assemble_mfma4<2, 6, true>), grid2, dim3(256), 0, s, APAP_K1_ARGS);
+        } else {
+            hipLaunchKernelGGL(k_assemble_valu, dim3((p.cell_tiles + 3) / 4, p.splits, batch), dim3(256), 0, s, APAP_K1_ARGS);
+        }
+#undef APAP_K1_ARGS
     }
     {
         ProfScope prof(ctx, APAP_PROF_EIGEN, s);
         const dim3 grid(p.cell_tiles, 1, batch);
-        if (apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI)
-            hipLaunchKernelGGL(k_eigen_denorm<false>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
-                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful, we);
-        else
-            hipLaunchKernelGGL(k_eigen_denorm<true>, grid, dim3(64), 0, s, moments, p.splits, cells, p.cells_pad, d_denorms,
-                               pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful, we);
+#define APAP_K2_ARGS moments, p.splits, cells, p.cells_pad, d_denorms, pick_rank, d_H, bs, d_tables, n, d_vertices, gamma, inv_sigma, careful, we
+        const bool jacobi = apap::opt(ctx, APAP_OPT_EIGEN_SOLVER) == APAP_EIGEN_JACOBI;
+        if (jacobi && m24) hipLaunchKernelGGL((k_eigen_denorm<false, true>), grid, dim3(64), 0, s, APAP_K2_ARGS);
+        else if (jacobi) hipLaunchKernelGGL((k_eigen_denorm<false, false>), grid, dim3(64), 0, s, APAP_K2_ARGS);
+        else if (m24) hipLaunchKernelGGL((k_eigen_denorm<true, true>), grid, dim3(64), 0, s, APAP_K2_ARGS);
+        else hipLaunchKernelGGL((k_eigen_denorm<true, false>), grid, dim3(64), 0, s, APAP_K2_ARGS);
+#undef APAP_K2_ARGS
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_solve_device launch");
@@ -3103,18 +3038,15 @@ int warp_impl(apap_ctx *ctx, const WarpArgs &a) {
     if (fast_ok) {
         ProfScope prof(ctx, APAP_PROF_WARP, s);
         const int rows = warp_kernel >= 8 ? 8 : warp_kernel >= 4 ? warp_kernel : 2;       // instantiated for 2, 4, 5, 6, 8
-#ifndef APAP_K3_BLOCK
-#define APAP_K3_BLOCK 256
-#endif
-        constexpr int kWpb = APAP_K3_BLOCK / 64;      // waves (= strips) per block
+        constexpr int kWpb = 256 / 64;      // waves (= strips) per block
         const dim3 grid((unsigned)((final_w + 255) / 256), (unsigned)((row_count + kWpb * rows - 1) / (kWpb * rows)), batch);
 #define APAP_LAUNCH_FAST(R)                                                                                          \
     if (d_center)                                                                                                    \
-        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
+        hipLaunchKernelGGL((k_warp_fast<true, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols,  \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out, d_center,           \
                            center_h, center_w, row_begin, row_count, st, a.status);                                  \
     else                                                                                                             \
-        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(APAP_K3_BLOCK), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
+        hipLaunchKernelGGL((k_warp_fast<false, R>), grid, dim3(256), 0, s, d_img, img_h, img_w, hinv_pad, mesh_rows, mesh_cols, \
                            lut, ww.frec, ww.fcol, ww.frow, final_w, final_h, off_x, off_y, d_out,                     \
                            (const uint8_t *)nullptr, 0, 0, row_begin, row_count, st, a.status)
         if (rows == 4) { APAP_LAUNCH_FAST(4); }

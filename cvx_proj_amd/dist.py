@@ -295,7 +295,8 @@ class ShardedSolver:
         self.denorm = torch.zeros(_native.DENORM_DOUBLES, dtype=torch.float64, device=dev)
         if self.rank == 0:
             q = _native.host_prepare(pair.src, pair.dst)
-            self.table.copy_(torch.from_numpy(_native.host_build_table(pair.src, q["cf1"], q["cf2"])))
+            self.table.copy_(torch.from_numpy(_native.host_build_table(pair.src, q["cf1"], q["cf2"],
+                                                                       moments=ctx.get("moments") if ctx is not None else 30)))
             self.denorm.copy_(torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])))
         self.H = torch.zeros((self.cells_total, 9), dtype=torch.float32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -502,16 +503,18 @@ class ShardedSolver:
         return self.out
 
 
-def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
+def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve, ctx=None):
     """Independent pairs dealt round-robin to the ranks; returns, on rank 0, the list of
-    H grids in input order (``None`` elsewhere).  All pairs must share one mesh shape."""
+    H grids in input order (``None`` elsewhere).  All pairs must share one mesh shape.  ``ctx``: the solver options (a
+    context with ``moments=24`` gets the 24-sum tables it needs)."""
+    moments = ctx.get("moments") if ctx is not None else 30
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     mine, tables, dens = [], [], []
     my_pairs = [pairs[k] for k in range(rank, len(pairs), world)]
     for p in my_pairs:
         q = _native.host_prepare(p.src, p.dst)
-        tables.append(torch.from_numpy(_native.host_build_table(p.src, q["cf1"], q["cf2"])))
+        tables.append(torch.from_numpy(_native.host_build_table(p.src, q["cf1"], q["cf2"], moments=moments)))
         dens.append(torch.from_numpy(_native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])))
     same = (len(my_pairs) > 1 and solve_fn is hip_solve
             and all(len(p.src) == len(my_pairs[0].src) and np.array_equal(p.vertices, my_pairs[0].vertices)
@@ -519,12 +522,12 @@ def solve_pairs(pairs, dev, dist=None, solve_fn=hip_solve):
     if same:   # one batched launch for this rank's pairs
         vert = torch.from_numpy(np.ascontiguousarray(my_pairs[0].vertices.reshape(-1, 2))).to(dev)
         Hb = hip_solve_batch(torch.stack(tables).to(dev), torch.stack(dens).to(dev), vert, my_pairs[0].gamma,
-                             my_pairs[0].sigma)
+                             my_pairs[0].sigma, ctx=ctx)
         mine = list(Hb)
     else:
         for p, table, den in zip(my_pairs, tables, dens):
             vert = torch.from_numpy(np.ascontiguousarray(p.vertices.reshape(-1, 2))).to(dev)
-            mine.append(solve_fn(table.to(dev), den.to(dev), vert, p.gamma, p.sigma))
+            mine.append(solve_fn(table.to(dev), den.to(dev), vert, p.gamma, p.sigma, **({"ctx": ctx} if ctx is not None else {})))
     if not _collective(dist, world):
         return [h.cpu().numpy().reshape(p.vertices.shape[0], p.vertices.shape[1], 3, 3) for h, p in zip(mine, pairs)]
     per_rank = (len(pairs) + world - 1) // world

@@ -204,7 +204,8 @@ class Pipeline:
         n = int(np.asarray(src).shape[0])
         nt, nd = n * _native.TABLE_STRIDE, _native.DENORM_DOUBLES
         stage = self._staging(nt + nd)
-        table = _native.host_build_table(src, q["cf1"], q["cf2"], out=stage[:nt].reshape(n, _native.TABLE_STRIDE))
+        table = _native.host_build_table(src, q["cf1"], q["cf2"], out=stage[:nt].reshape(n, _native.TABLE_STRIDE),
+                                         moments=self.ctx.get("moments") if self.ctx is not None else 30)
         _native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"], out=stage[nt:nt + nd])
         t1 = time.perf_counter()
         with torch.cuda.device(self.dev):

@@ -53,7 +53,8 @@ extern "C" {
 #define APAP_HINV_STRIDE 10
 
 /* Solver variants (APAP_OPT_SOLVER_VARIANT).  All produce the same float32 grids on the golden
- * vectors; they differ in the summation order of the 30 moment sums. */
+ * vectors; they differ in the summation order of the 30 moment sums.  With APAP_OPT_MOMENTS = 24: AUTO / MFMA = one
+ * 16x16x4 + two 4x4x4_4b instructions per step, MFMA4 / MFMA4X2 = six 4x4x4_4b; VALU is refused. */
 #define APAP_VARIANT_AUTO 0
 #define APAP_VARIANT_VALU 1 /* one lane per cell, fp64 FMA accumulation            */
 #define APAP_VARIANT_MFMA 2 /* v_mfma_f64_16x16x4_f64 accumulation, table via LDS  */
@@ -82,8 +83,8 @@ extern "C" {
  * float* where the context goes.  Such a caller must refuse to run: check apap_abi_version() ==
  * APAP_ABI_VERSION once after loading (cvx_proj_amd/_native.py does); a generation-1 library does not
  * export the symbol at all.  Bump on any change of an existing signature. */
-#define APAP_ABI_VERSION 5
-#define APAP_ABI_VERSION_STRING "0.5"
+#define APAP_ABI_VERSION 6
+#define APAP_ABI_VERSION_STRING "0.6"
 
 /* ---------------------------------------------------------------- diagnostics --- */
 const char *apap_last_error(void);
@@ -129,7 +130,19 @@ typedef struct apap_ctx apap_ctx;
                                       whatever the call holds - a shard of a mesh (cvx_proj_amd/dist.py) then sums every
                                       cell's keypoints in the order the whole mesh would on one GPU: the same bits for any
                                       number of ranks, at the price of fewer, larger blocks per GPU                      */
-#define APAP_OPT_COUNT 11
+#define APAP_OPT_MOMENTS 11         /* 30 (default): K1 sums the 30 distinct entries of A^T W^2 A with the reference's
+                                      float32-ROUNDED DLT products kept verbatim (apap.py:103-119): grids bit-identical to the
+                                      reference's.  24 (opt-in): the 24 sums of the EXACT products (SURVEY.md section 8a:
+                                      [[S0,0,Sx],[0,S0,Sy],[Sx,Sy,Sr]]) - a quarter less matrix-pipe work in K1, a fifth less
+                                      slab traffic; NOT bit-identical: one float32 ulp in a few per cent of a grid's entries
+                                      (reprojection-RMSE delta < 1e-4 px on BASELINE's configurations, tests/test_gpu_moments24.py).
+                                      The device entry points then expect the table of apap_host_build_table24 (a table of the
+                                      other layout gives NaN grids); the host-buffer entry points build the right one themselves.
+                                      No fused small-mesh launch, no VALU variant in this mode                             */
+#define APAP_OPT_WEIGHTS_F32 12     /* 0 (default).  1 (opt-in, honoured with APAP_OPT_MOMENTS = 24 only): K1 evaluates w^2 in
+                                      float32 (v_sqrt_f32, v_exp_f32: ~2e-7 relative) instead of float64; the sums stay
+                                      float64.  Same class of result as MOMENTS = 24 alone (one float32 ulp here and there)  */
+#define APAP_OPT_COUNT 13
 apap_ctx *apap_ctx_create(void);
 void apap_ctx_destroy(apap_ctx *ctx); /* frees the pooled device buffers and pending events; NULL is a no-op */
 int apap_ctx_set_option(apap_ctx *ctx, int option, int value);
@@ -173,6 +186,13 @@ int apap_host_build_table_rows(const double *src, const float *aa, int n, double
  * and the 36-double de-normalisation block. */
 int apap_host_build_table(const float *src, const float *cf1, const float *cf2, int n,
                           double *table);
+/* The table of APAP_OPT_MOMENTS = 24, from the same DLT rows `aa` (2n x 9 float32) and source keypoints: with p = (x, y, 1)
+ * and c = -x', f = -y' as `aa` holds them (aa[k][0..1], aa[2k][8], aa[2k+1][8]), and pp = (xx, xy, x, yy, y, 1) -
+ *   [0..5] pp   [6..11] c pp   [12..17] f pp   [18..23] (c^2 + f^2) pp     (float64 products of the float32 values)
+ *   [24..27] the rows' own float32 products aa[2k][6], aa[2k][7], aa[2k+1][6], aa[2k+1][7] (the careful path re-solves from
+ *            the reference's rows), [28] the layout marker (a quiet NaN), [29] the source keypoint as two float32
+ *            (APAP_OPT_WEIGHTS_F32), [30,31] the source keypoint (x, y) as float64. */
+int apap_host_build_table24(const double *src, const float *aa, int n, double *table);
 int apap_host_build_denorm(const float *iC2, const float *C1, const float *iN2, const float *N1,
                            double *denorm);
 

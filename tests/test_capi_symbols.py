@@ -46,7 +46,8 @@ def test_contexts_hold_the_options_not_the_process(native):
     v = ctypes.c_int(-1)
     assert native.lib().apap_ctx_get_option(None, native.OPT_WANT_WAVES, ctypes.byref(v)) == native.OK and v.value == 4096
     assert native.lib().apap_ctx_set_option(None, native.OPT_CAREFUL, 0) == native.ERR_INVALID_ARG      # NULL cannot be changed
-    for name, bad in (("variant", 9), ("eigen", -1), ("careful", 2), ("warp_rows", 3), ("want_waves", 0)):
+    assert (b.get("moments"), b.get("weights_f32")) == (30, 0)           # the bit-identical form is the default
+    for name, bad in (("variant", 9), ("eigen", -1), ("careful", 2), ("warp_rows", 3), ("want_waves", 0), ("moments", 25), ("weights_f32", 2)):
         with pytest.raises(ValueError):
             b.set(name, bad)
     # the workspace a solve needs follows the context's variant, not a global
@@ -55,6 +56,9 @@ def test_contexts_hold_the_options_not_the_process(native):
     ws_valu = native.lib().apap_solve_workspace_bytes(native._h(a), n, cells)
     assert ws_default > 0 and ws_valu > 0 and ws_valu != ws_default
     assert native.lib().apap_solve_workspace_bytes(native._h(b), n, cells) == ws_default
+    c24 = native.Context(moments=24)
+    assert native.lib().apap_solve_workspace_bytes(native._h(c24), n, cells) * 30 == ws_default * 24     # 24 of 30 slab rows
+    c24.close()
     prof = a.profile_read()
     assert set(prof) == set(native.PROF_NAMES) and all(v == (0.0, 0) for v in prof.values())
     import threading

@@ -70,6 +70,26 @@ def test_c_prepare_matches_oracle_random(native):
         assert np.array_equal(table[:, 30:], src.astype(np.float64))
         # the block structure the kernels rely on
         assert np.array_equal(P[:, 3:6, 3:6], P[:, 0:3, 0:3]) and not P[:, 0:3, 3:6].any()
+        # the opt-in 24-sum table (APAP_OPT_MOMENTS = 24): exact float64 products of the rows' float32 entries
+        t24 = native.host_build_table(src, q["cf1"], q["cf2"], moments=24)
+        a64 = aa.astype(np.float64)
+        x, y, c, f = a64[0::2, 0], a64[0::2, 1], a64[0::2, 8], a64[1::2, 8]
+        pp = np.stack([x * x, x * y, x, y * y, y, np.ones_like(x)], axis=1)
+        r = c * c + f * f
+        assert np.array_equal(t24[:, :24], np.concatenate([pp, c[:, None] * pp, f[:, None] * pp, r[:, None] * pp], axis=1))
+        assert np.array_equal(t24[:, 24:28], np.stack([a64[0::2, 6], a64[0::2, 7], a64[1::2, 6], a64[1::2, 7]], axis=1))
+        assert (t24[:, 28].view(np.int64) == 0x7ff8242424242424).all()
+        assert np.array_equal(t24[:, 29].copy().view(np.float32).reshape(-1, 2), src) and np.array_equal(t24[:, 30:], src.astype(np.float64))
+        # ... of which the normal matrix is the block form of SURVEY.md section 8a, equal to the 30-sum one up to the float32
+        # rounding of the reference's products
+        S = t24[:, :24].sum(axis=0)
+        M = np.zeros((9, 9))
+        tri = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+        for u, (i, j) in enumerate(tri):
+            for (bi, bj, k) in ((0, 0, 0), (1, 1, 0), (0, 2, 1), (1, 2, 2), (2, 2, 3)):
+                M[3 * bi + i, 3 * bj + j] = M[3 * bi + j, 3 * bj + i] = S[6 * k + u]
+        M = np.triu(M) + np.triu(M, 1).T
+        assert np.allclose(M, P.sum(axis=0), rtol=0, atol=3e-7 * np.abs(P.sum(axis=0)).max())
         den = native.host_build_denorm(q["iC2"], q["C1"], q["iN2"], q["N1"])
         assert np.array_equal(den, np.concatenate([q[k].astype(np.float64).ravel() for k in ("iC2", "C1", "iN2", "N1")]))
 
