@@ -150,12 +150,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ApapError(ERR_NO_DEVICE, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; "
                                            "g.build()'` or `make -C cvx_proj_amd/csrc`")
-        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (same
-        # SONAME as /opt/rocm's, different file); if this library pulled in /opt/rocm's
-        # copy first, a later `import torch` would load a second runtime that sees no
-        # GPU.  Importing torch first makes both share torch's copy; without torch (or
-        # with APAP_HIP_STANDALONE=1) the RPATH to /opt/rocm/lib is used.
-        if "torch" not in sys.modules and os.environ.get("APAP_HIP_STANDALONE", "0") != "1":
+        # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's, different
+        # file).  When torch is ALREADY imported its copy is in the process and this library binds to it; otherwise the RPATH
+        # to /opt/rocm/lib is used and NO torch is imported on the library's behalf (2.3 s against 0.4 s of start-up for a
+        # command that needs none: python -m cvx_proj_amd.apap).  The rule for a process that uses both: import torch BEFORE
+        # the first call into this module (cvx_proj_amd.pipeline and cvx_proj_amd.dist do so at their top; a later
+        # `import torch` would find /opt/rocm's runtime under its own SONAME and see no GPU).  APAP_HIP_PRELOAD_TORCH=1
+        # restores the old behaviour (torch imported here first, if it is installed).
+        if "torch" not in sys.modules and os.environ.get("APAP_HIP_PRELOAD_TORCH", "0") == "1":
             try:
                 import torch  # noqa: F401
             except ImportError:
@@ -252,9 +254,12 @@ def as_f32(a, shape_tail=None):
 
 
 def as_points(a):
-    """Keypoints in the dtype the reference would compute with: float32 stays float32 (what utils.get_features returns),
-    everything else - float64, float16, integers - is taken as float64 (numpy's own reductions promote integers to float64;
-    nothing in apap.py:35-100 casts its argument).  Returns (contiguous (n, 2) array, is_float64)."""
+    """Keypoints in the dtype the reference would compute with: float32 stays float32 (what utils.get_features returns);
+    float64 and integer arrays are taken as float64 (numpy's own reductions promote integers to float64; nothing in
+    apap.py:35-100 casts its argument) - both pinned bit for bit by tests/golden/f64pts_ref.npz.  Any OTHER dtype (float16,
+    longdouble, bool, ...) is widened to float64 as well, which is NOT what numpy does with it in the reference (a float16
+    set mixes with the float32 padding to float32 there): accepted, but without the bit-compatibility claim.
+    Returns (contiguous (n, 2) array, is_float64)."""
     a = np.asarray(a)
     a = np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
     if a.shape[-1:] != (2,):

@@ -10,9 +10,16 @@ Command line (reference apap.py:220-265 takes ``[case_idx] [img_idx]`` and reads
 dataset that is not distributed; the positional arguments and the output file are kept,
 the inputs come from ``--pair``)::
 
-    python -m cvx_proj_amd.apap [case_idx] [img_idx] [--data-root DIR | --pair pair.npz | --synth C1]
+    python -m cvx_proj_amd.apap [case_idx] [img_idx] [--cases 1-4 --imgs 1,2,4,5]
+                                [--data-root DIR | --pair pair.npz | --synth C1]
                                 [--config configs/case1.txt] [--out-prefix ../diff_1/results/]
                                 [--mesh-size 100] [--gamma 0.5] [--sigma 100] [--warp out.npy | --stitch out.npy]
+                                [--resident] [--timing]
+
+The command goes through the host-buffer entry points of the C ABI (``apap_local_homography_pts``, ``apap_local_warp``,
+``apap_invert_normalize_flatten``): no torch in the process - a pair is ~1 ms of GPU work, importing torch costs 2 s.
+``--resident`` takes :mod:`cvx_proj_amd.pipeline` instead (torch for device memory; what a caller with many pairs in flight
+uses).
 """
 from __future__ import annotations
 
@@ -282,11 +289,30 @@ def run_pair_by_calls(src, dst, H_global, other_shape, center_shape, mesh_size=1
     return flat, warped
 
 
+def _parse_jobs(a, ap):
+    """The (case_idx, img_idx) pairs of one invocation: the two positionals of apap.py:225-232, or the loop of
+    ``--cases a-b --imgs i,j,...`` (the pattern of the reference's run_all.sh:4-31: 4 cases x pictures 1 2 4 5 in ONE process -
+    one start-up of the interpreter, the runtime and the code objects for all of them)."""
+    if a.cases is None and a.imgs is None:
+        return [(a.case_idx, a.img_idx)]
+    try:
+        lo, _, hi = (a.cases or str(a.case_idx)).partition("-")
+        cases = range(int(lo), int(hi or lo) + 1)
+        imgs = [int(v) for v in (a.imgs or str(a.img_idx)).split(",")]
+    except ValueError:
+        ap.error("--cases takes a or a-b, --imgs a comma-separated list of picture indices")
+    return [(c, i) for c in cases for i in imgs]
+
+
 def main(argv=None):
     import argparse
+    import time
+    t_start = time.perf_counter()
     ap = argparse.ArgumentParser(prog="cvx_proj_amd.apap", description=__doc__.split("\n\n")[0])
     ap.add_argument("case_idx", nargs="?", type=int, default=1)
     ap.add_argument("img_idx", nargs="?", type=int, default=1)
+    ap.add_argument("--cases", help="a or a-b: loop over these cases in one process (with --imgs; run_all.sh's pattern)")
+    ap.add_argument("--imgs", help="comma-separated picture indices to loop over, e.g. 1,2,4,5")
     ap.add_argument("--pair", help=".npz with src, dst (n,2), H (3,3), other_shape, center_shape[, other_img]")
     ap.add_argument("--synth", help="use a synthetic configuration of cvx_proj_amd.synth (C1..C5)")
     ap.add_argument("--data-root", help="the reference's own flow (apap.py:236-238): read case{c}/scat/img_haze{i}.png and "
@@ -301,6 +327,10 @@ def main(argv=None):
     ap.add_argument("--stitch", help="run the fused warp + blend with the centre image (the reference's "
                                      "commented-out tail, apap.py:258-262) and save the canvas to this .npy")
     ap.add_argument("--device", type=int, default=-1)
+    ap.add_argument("--resident", action="store_true",
+                    help="one resident pass per pair through cvx_proj_amd.pipeline (imports torch: ~2 s more start-up, ~0.3 ms less "
+                         "per pair); default: the host-buffer entry points of the C ABI, no torch in the process")
+    ap.add_argument("--timing", action="store_true", help="print the stages' wall times as one JSON line on stderr")
     a = ap.parse_args(argv)
 
     par = {"mesh_size": 100, "gamma": 0.5, "sigma": 100.0}     # apap.py:221-223
@@ -313,54 +343,88 @@ def main(argv=None):
         v = getattr(a, k)
         if v is not None:
             par[k] = v
+    if not (a.pair or a.data_root or a.synth):
+        ap.error("the reference's dataset (../diff_1) is not distributed: give --data-root, --pair or --synth")
+    jobs = _parse_jobs(a, ap)
+    stages = {"imports_ms": (time.perf_counter() - t_start) * 1e3}
 
     pipeline = None
-    if a.pair:
-        z = np.load(a.pair)
-        src, dst, Hg = z["src"], z["dst"], z["H"]
-        other_shape, center_shape = tuple(z["other_shape"]), tuple(z["center_shape"])
-        other_img = z["other_img"] if ((a.warp or a.stitch) and "other_img" in z) else None
-        center_img = z["center_img"] if (a.stitch and "center_img" in z) else None
-    elif a.data_root:
-        from .baseline_stitch_test import CENTER_PIC_ID, visualize_feature_pairs
+    t0 = time.perf_counter()
+    if a.resident:
+        import torch  # noqa: F401  (before the library is loaded: one HIP runtime per process, _native.lib)
         from .pipeline import Pipeline
-        from .utils import get_no_scat_img, get_path, imread
         pipeline = Pipeline(device=a.device)
-        shapes = []
-        for idx in (CENTER_PIC_ID, a.img_idx):       # visualize_equalized_hist (apap.py:236-237), left on the device:
-            path = get_path(a.case_idx, idx, root=a.data_root)      # the reference only shows the pictures and reads their shape
-            img = imread(path)
-            if img is None:
-                raise FileNotFoundError(path)
-            pipeline.equalize(img, name=f"eq{idx}")
-            shapes.append(img.shape)
-        center_shape, other_shape = shapes
-        src, dst, Hg = visualize_feature_pairs(None, None, case_idx=a.case_idx, pic_id=a.img_idx, swap=True,
-                                               root=a.data_root, device=a.device)
-        other_img = center_img = None
-        if a.warp or a.stitch:      # the blend uses the haze-free pictures (apap.py:245,258-262)
-            center_img, other_img = get_no_scat_img(a.case_idx, a.img_idx, CENTER_PIC_ID, root=a.data_root)
-            if not a.stitch:
-                center_img = None
-    elif a.synth:
-        from .synth import CONFIGS, synth_pair
-        w, h, n, m, seed = CONFIGS[a.synth]
-        if a.mesh_size is None and not a.config:
-            par["mesh_size"] = m
-        p = synth_pair(w, h, n, par["mesh_size"], seed, with_image=bool(a.warp or a.stitch))
-        src, dst, Hg, other_shape, center_shape, other_img = p.src, p.dst, p.Hg, p.shape, p.shape, p.img
-        center_img = (np.random.default_rng(seed + 1).integers(0, 256, p.shape, dtype=np.uint8) if a.stitch else None)
     else:
-        ap.error("the reference's dataset (../diff_1) is not distributed: give --data-root, --pair or --synth")
+        if _native.lib().apap_device_count() < 1:       # loads the library, initialises the runtime
+            raise _native.ApapError(_native.ERR_NO_DEVICE, "no HIP device; there is no CPU fallback")
+    stages["runtime_init_ms"] = (time.perf_counter() - t0) * 1e3
+    stages["pairs"] = []
 
-    flat, warped = run_pair(src, dst, Hg, other_shape, center_shape, par["mesh_size"], par["gamma"], par["sigma"],
-                            other_img=other_img, center_img=center_img, device=a.device, pipeline=pipeline)
-    print(f"local_homography shape: {(par['mesh_size'], par['mesh_size'], 3, 3)}")
-    out_dir = f"{a.out_prefix}case{a.case_idx}"
-    os.makedirs(out_dir, exist_ok=True)
-    save2mat(f"case{a.case_idx}/H3{a.img_idx}_apap", flat, name="H", prefix=a.out_prefix)
-    if (a.warp or a.stitch) and warped is not None:
-        np.save(a.stitch or a.warp, warped)
+    for case_idx, img_idx in jobs:
+        t0 = time.perf_counter()
+        mesh_size = par["mesh_size"]
+        if a.pair:
+            z = np.load(a.pair)
+            src, dst, Hg = z["src"], z["dst"], z["H"]
+            other_shape, center_shape = tuple(z["other_shape"]), tuple(z["center_shape"])
+            other_img = z["other_img"] if ((a.warp or a.stitch) and "other_img" in z) else None
+            center_img = z["center_img"] if (a.stitch and "center_img" in z) else None
+        elif a.data_root:
+            from .baseline_stitch_test import CENTER_PIC_ID, visualize_feature_pairs
+            from .utils import equalize_hist, get_no_scat_img, get_path, imread
+            shapes = []
+            for idx in (CENTER_PIC_ID, img_idx):         # visualize_equalized_hist (apap.py:236-237): the reference shows the
+                path = get_path(case_idx, idx, root=a.data_root)        # pictures and goes on with their shape
+                img = imread(path)
+                if img is None:
+                    raise FileNotFoundError(path)
+                if pipeline is not None:
+                    pipeline.equalize(img, name=f"eq{idx}")
+                else:
+                    equalize_hist(img, device=a.device)
+                shapes.append(img.shape)
+            center_shape, other_shape = shapes
+            src, dst, Hg = visualize_feature_pairs(None, None, case_idx=case_idx, pic_id=img_idx, swap=True,
+                                                   root=a.data_root, device=a.device)
+            other_img = center_img = None
+            if a.warp or a.stitch:      # the blend uses the haze-free pictures (apap.py:245,258-262)
+                center_img, other_img = get_no_scat_img(case_idx, img_idx, CENTER_PIC_ID, root=a.data_root)
+                if not a.stitch:
+                    center_img = None
+        else:
+            from .synth import CONFIGS, synth_pair
+            w, h, n, m, seed = CONFIGS[a.synth]
+            if a.mesh_size is None and not a.config:
+                mesh_size = m
+            # in a loop every (case, picture) is a pair of its own: the first one is the configuration's own seed
+            seed += (case_idx - jobs[0][0]) * 16 + (img_idx - jobs[0][1])
+            p = synth_pair(w, h, n, mesh_size, seed, with_image=bool(a.warp or a.stitch))
+            src, dst, Hg, other_shape, center_shape, other_img = p.src, p.dst, p.Hg, p.shape, p.shape, p.img
+            center_img = (np.random.default_rng(seed + 1).integers(0, 256, p.shape, dtype=np.uint8) if a.stitch else None)
+        t1 = time.perf_counter()
+        if pipeline is not None:
+            flat, warped = run_pair(src, dst, Hg, other_shape, center_shape, mesh_size, par["gamma"], par["sigma"],
+                                    other_img=other_img, center_img=center_img, device=a.device, pipeline=pipeline)
+        else:
+            flat, warped = run_pair_by_calls(src, dst, Hg, other_shape, center_shape, mesh_size, par["gamma"], par["sigma"],
+                                             other_img=other_img, center_img=center_img, device=a.device)
+        t2 = time.perf_counter()
+        print(f"local_homography shape: {(mesh_size, mesh_size, 3, 3)}")
+        out_dir = f"{a.out_prefix}case{case_idx}"
+        os.makedirs(out_dir, exist_ok=True)
+        save2mat(f"case{case_idx}/H3{img_idx}_apap", flat, name="H", prefix=a.out_prefix)
+        if (a.warp or a.stitch) and warped is not None:
+            out = a.stitch or a.warp
+            if len(jobs) > 1:
+                root, ext = os.path.splitext(out)
+                out = f"{root}_case{case_idx}_{img_idx}{ext}"
+            np.save(out, warped)
+        stages["pairs"].append({"case": case_idx, "img": img_idx, "inputs_ms": (t1 - t0) * 1e3, "compute_ms": (t2 - t1) * 1e3,
+                                "save_ms": (time.perf_counter() - t2) * 1e3})
+    stages["total_ms"] = (time.perf_counter() - t_start) * 1e3
+    if a.timing:
+        import json
+        print(json.dumps(stages), file=sys.stderr, flush=True)
     return 0
 
 

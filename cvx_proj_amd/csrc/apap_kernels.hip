@@ -1723,10 +1723,15 @@ __device__ __forceinline__ void fast_record(const double (&h)[9], bool origin_ok
     const double n0x = floor(Qx), n0y = floor(Qy);
     const double Ax = fma(-Qx, h[6], h[0]), Bx = fma(-Qx, h[7], h[1]);
     const double Ay = fma(-Qy, h[6], h[3]), By = fma(-Qy, h[7], h[4]);
-    // |s| / 2^22 <= (|c'| + |a'| DX + |b'| DY) / tmin <= M + f (at2 + g) / tmin,  f < 1.25
+    // |s| / 2^16 <= (|c'| + |a'| DX + |b'| DY) / tmin <= M + f (at2 + g) / tmin,  f < 1.25
     const double Mx = (fabs(Ax) * DX + fabs(Bx) * DY) / tmin, My = (fabs(Ay) * DX + fabs(By) * DY) / tmin;
     const double Smax = fmax(Mx, My) + 1.25 * rho;
-    ok = ok && Smax < 500.0;
+    // The estimate is a 16.16 fixed-point number: its integer half is a SIGNED 16 bits, so |estimate| must stay far below
+    // 2^15 pixels - a saturated v_cvt_flr_i32_f32 (INT_MAX: fraction 0xffff) would pass the doubt test.  kFastMaxEstimate
+    // keeps it two powers of two inside; cells whose bound is larger take the exact path for every pixel.
+    constexpr double kFastMaxEstimate = 500.0;
+    static_assert(kFastMaxEstimate * 4 < (double)(1 << (31 - kFastFracBits)), "the estimate's integer half must fit the fixed-point format");
+    ok = ok && Smax < kFastMaxEstimate;
     // float32 side, relative to |s|: 3 (inputs + two FMA roundings of the numerator) + 3 rho (the same of
     // the denominator) + 2 (v_rcp_f32, 1 ulp) + 1 (the product); 0.5 on top for second-order terms
     const double E32 = (6.5 + 3.0 * rho) * eps32 * Smax;

@@ -151,6 +151,19 @@ class WarpPlan:
         self.work = torch.zeros(self.nbytes, dtype=torch.uint8, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self._phase(_native.WARP_GEOMETRY)
+        # The kernels only OR bits into the status word.  What the geometry phase found (bit 1: the edges do not cover the
+        # canvas) holds for the plan's whole life and is kept apart; the word itself then serves one pair at a time
+        # (begin() before a pair's phases, status_word() after them), so that one pair's singular grid is not every later pair's.
+        self.geo_status = int(self.status.cpu()[0])
+        self.status.zero_()
+
+    def begin(self):
+        """Clear the per-pair status bits (singular cell, unprepared workspace) before a pair's phases."""
+        self.status.zero_()
+
+    def status_word(self):
+        """This pair's status bits together with the geometry phase's (synchronises)."""
+        return int(self.status.cpu()[0]) | self.geo_status
 
     def _phase(self, phases, imgs=None, H=None, out=None, centers=None, rows=None, hinv_out=None):
         fw, fh, ox, oy = self.geo
@@ -249,7 +262,7 @@ class ShardedSolver:
     """
 
     def __init__(self, pair, dev, dist=None, solve_fn=hip_solve, warp_fn=hip_warp_rows, ctx=None, overlap="auto",
-                 same_bits=False):
+                 same_bits=False, resident_warp=False):
         self.pair, self.dev, self.dist, self.solve_fn, self.warp_fn = pair, dev, dist, solve_fn, warp_fn
         self.rank = dist.get_rank() if dist is not None else 0
         self.world = dist.get_world_size() if dist is not None else 1
@@ -314,9 +327,17 @@ class ShardedSolver:
         # the resident warp form (default engine, bands aligned to the rank's mesh rows): a WarpPlan over the rank's OWN mesh
         # rows - canvas row / column tables built once, the per-cell half in the tail of the rank's solve -, so that a warp
         # step is the gather kernel alone, as on one GPU (_make_plan)
+        # The plan is made when a warp is first asked for (warp() / step(), or resident_warp=True): a caller that only wants the
+        # H grid pays neither the canvas-sized workspace nor the ~160 bytes per cell the warp-ready tail of K2 writes.
         self._plan = None
         self._plan_tried = False
         self._cells_ready = False
+        self._want_plan = bool(resident_warp)
+
+    def status_word(self):
+        """The device status bits of this solver's warps (the plan's geometry bits included; synchronises)."""
+        geo = self._plan.geo_status if self._plan is not None else 0
+        return int(self.status.cpu()[0]) | geo
 
     def broadcast_inputs(self):
         """Keypoint table (n x 256 B) and de-normalisation block from rank 0 to every rank:
@@ -375,7 +396,7 @@ class ShardedSolver:
     def _solve_piece(self, k):
         """Launch piece k of this rank's rows into its (padded) shard buffer."""
         vert, mine = self._vert[k], self._mine[k]
-        plan = self._make_plan() if not self.overlap and self.solve_fn is hip_solve else None
+        plan = self._make_plan() if self._want_plan and not self.overlap and self.solve_fn is hip_solve else None
         if plan is not None and vert.shape[0] == plan.rows * plan.cols:
             # the rank's rows in ONE launch whose tail leaves every cell warp ready in the plan's workspace
             plan.solve(self.table, self.denorm, vert, self.pair.gamma, self.pair.sigma, out=mine, work=self._solve_kw.get("work"))
@@ -427,6 +448,7 @@ class ShardedSolver:
     def step(self, gather_canvas=False):
         """One pipelined step of the pair: solve this rank's rows, start the all-gather of the H grid, warp this
         rank's band FROM ITS OWN ROWS while the gather runs, then wait for the gather.  Returns ``(H, band or canvas)``."""
+        self._want_plan = True
         self.solve(wait=False)
         band = self.warp(gather=gather_canvas)
         return self.finish(), band
@@ -466,6 +488,7 @@ class ShardedSolver:
         ``gather=False`` stops after the band: the canvas stays distributed (rank r holds rows
         ``self.bands[r]`` in ``self._band``) - what a pipeline that writes or consumes the bands in
         place does, and the part of the step that scales; returns this rank's band."""
+        self._want_plan = True          # from now on the solve's tail leaves the rank's cells warp ready
         if not hasattr(self, "img"):
             self._warp_setup()
         p, d = self.pair, self.dist
@@ -557,8 +580,8 @@ def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=Fals
     rank's pairs - 27 MB per 4K canvas: they stay where they were computed - or, with ``gather=True``, on rank 0 the
     list of all canvases as numpy arrays in input order (``None`` on the other ranks): for tests and small batches.
     ``plans``: a dict the CALLER keeps between calls - the rank's WarpPlan (workspace + the canvas row / column tables of this
-    geometry) is left in it, so that a later call on the same geometry and share of pairs skips the geometry phase and
-    allocates nothing (default engine only)."""
+    geometry) is left in it, so that a later call on the same geometry, share of pairs and context skips the geometry phase and
+    allocates no workspace (default engine only; the stacks of grids and images and the canvases are still made per call)."""
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
     mine = list(range(rank, len(pairs), world))
@@ -576,18 +599,21 @@ def warp_pairs(pairs, grids, dev, dist=None, warp_fn=hip_warp_batch, gather=Fals
         mesh_h = torch.from_numpy(np.ascontiguousarray(p0.mesh[1], dtype=np.float64)).to(dev)
         kw = {"ctx": ctx} if ctx is not None else {}
         if plans is not None and warp_fn is hip_warp_batch and len(p0.mesh[0]) <= 4096 and len(p0.mesh[1]) <= 4096:
-            key = (rows, cols, p0.final_w, p0.final_h, p0.off_x, p0.off_y, len(mine), str(dev), p0.mesh.tobytes())
+            # (a plan is bound to its context's options and to the dtype the edges were given in)
+            key = (rows, cols, p0.final_w, p0.final_h, p0.off_x, p0.off_y, len(mine), str(dev), id(ctx), p0.mesh.dtype.str,
+                   p0.mesh.tobytes())
             plan = plans.get(key)
             if plan is None:
                 plan = plans[key] = WarpPlan(p0.mesh, (rows, cols), p0.final_w, p0.final_h, p0.off_x, p0.off_y, dev, batch=len(mine), ctx=ctx)
+            plan.begin()
             plan.cells(H.view(-1, 9))
-            out, status = plan.gather(imgs), plan.status
+            out, word = plan.gather(imgs), plan.status_word()
         else:
             out, status = warp_fn(imgs, H, mesh_w, mesh_h, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (rows, cols), **kw)
-        if status is not None and int(status.cpu()[0]) != 0:
-            word = int(status.cpu()[0])
+            word = int(status.cpu()[0]) if status is not None else 0
+        if word != 0:
             code = _native.ERR_SINGULAR if word & 1 else _native.ERR_INDEX if word & 2 else _native.ERR_INVALID_ARG
-            raise _native._ERROR_CLASSES[code](code, "warp_pairs: device status word %d" % int(status.cpu()[0]))
+            raise _native._ERROR_CLASSES[code](code, "warp_pairs: device status word %d" % word)
         canv = {k: out[i] for i, k in enumerate(mine)}
     if not gather:
         return canv

@@ -38,6 +38,11 @@ class Pipeline:
     """Resident APAP pass.  ``device``: HIP device index (-1 = current); ``ctx``: a ``_native.Context``."""
 
     def __init__(self, device=-1, ctx=None):
+        import sys
+        if _native._lib is not None and "torch" not in sys.modules:
+            raise _native.ApapError(_native.ERR_HIP, "cvx_proj_amd's library was loaded before torch was imported: this process already "
+                                                     "runs /opt/rocm's HIP runtime, torch would not see the GPU through it.  Import torch "
+                                                     "before the first call into cvx_proj_amd (or set APAP_HIP_PRELOAD_TORCH=1)")
         import torch
         if not torch.cuda.is_available():
             raise _native.ApapError(_native.ERR_NO_DEVICE, "Pipeline needs a HIP device; there is no CPU fallback")
@@ -226,7 +231,7 @@ class Pipeline:
             d_work = self._get("solve_work", (nb,), torch.uint8)
             if plan is not None:
                 # the solve that leaves every cell warp ready in the plan's workspace (apap_solve_warp_batch_device)
-                plan.status.zero_()
+                plan.begin()        # this pair's status bits; the geometry phase's are kept in plan.geo_status
                 mark("small uploads done")
                 plan.solve(d_table, d_den, d_vert, float(gamma), float(sigma), out=d_H, work=d_work)
                 mark("solve done")
@@ -306,7 +311,7 @@ class Pipeline:
                     flat = self._flat_host[:cells * 9].numpy().reshape(cells, 9).copy()
                 canvas = self._down(d_out) if d_out is not None else None      # (synchronises the main stream)
             main.synchronize()
-            status = int(self._status_host[0])
+            status = int(self._status_host[0]) | (plan.geo_status if plan is not None else 0)
             grid = self._down(d_H).reshape(rows, cols, 3, 3) if want_grid else None
         t3 = time.perf_counter()
         if marks:

@@ -29,6 +29,10 @@ def golden():
 @pytest.fixture(scope="session")
 def native():
     """The ctypes binding; building the library first if it is missing."""
+    try:
+        import torch  # noqa: F401  (tests of the resident forms use torch: it must be in the process BEFORE the library is loaded)
+    except ImportError:
+        pass
     from cvx_proj_amd import _native
     if not os.path.exists(_native.LIB_PATH):
         import __graft_entry__ as g

@@ -162,3 +162,16 @@ def test_plan_cells_option_fixes_the_launch_plan(native):
     with pytest.raises(native.ApapError):
         ctx.set("plan_cells", -1)
     ctx.close()
+
+
+def test_the_command_line_needs_no_torch():
+    """importing the drop-in module and loading the library must not pull torch into the process (2 s of
+    start-up for ~1 ms of GPU work); torch is borrowed only when it is already there."""
+    import subprocess
+    import sys
+    code = ("import sys; import cvx_proj_amd.apap as A; from cvx_proj_amd import _native; _native.lib(); "
+            "import cvx_proj_amd.utils, cvx_proj_amd.baseline_stitch_test, cvx_proj_amd.synth, cvx_proj_amd.evaluate; "
+            "assert 'torch' not in sys.modules, 'torch was imported'; print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-1500:]

@@ -65,6 +65,21 @@ def test_c5_batched_warp_vs_reference(native, golden):
     assert list(plans.values()) == [plan] and int(plan.status.cpu()[0]) == 0
     for k in range(4):
         assert torch.equal(again[k], canv[k]) and torch.equal(again2[3 - k], canv[k])
+    # the kernels only OR bits into a plan's status word.  A singular grid on a kept plan must fail THAT call and not
+    # every later one on the same plan; what the geometry phase found is kept apart (plan.geo_status)
+    bad = [g.copy() for g in grids]
+    bad[2][17, 5] = 0.0                    # one singular cell
+    with pytest.raises(np.linalg.LinAlgError):
+        warp_pairs(pairs, bad, dev, plans=plans)
+    after = warp_pairs(pairs, grids, dev, plans=plans)
+    assert list(plans.values()) == [plan] and plan.geo_status == 0 and plan.status_word() == 0
+    for k in range(4):
+        assert torch.equal(after[k], canv[k])
+    # ... and another context is another plan (a plan is bound to its context's options)
+    other = native.Context(warp_rows=4)
+    warp_pairs(pairs, grids, dev, plans=plans, ctx=other)
+    assert len(plans) == 2
+    other.close()
     # the inverses the batch entry point writes back (what the reference leaves in its argument), all pairs at once
     H = torch.stack([torch.from_numpy(g.reshape(-1, 9)) for g in grids]).to(dev)
     imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)

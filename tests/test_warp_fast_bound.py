@@ -87,6 +87,31 @@ def test_random_projective_cells():
     assert rec["good"].mean() > 0.5
 
 
+def test_estimates_near_the_fixed_point_limit():
+    """The 16.16 estimate keeps a SIGNED 16-bit integer half: the record must refuse a cell whose estimate could leave it
+    (|estimate| bound >= 500 px, kFastMaxEstimate of apap_kernels.hip), and be exact right up to that cap - magnifications of
+    2 ... 6 over cells of up to 127 px put the bound between ~250 and ~800 px on either side of it."""
+    rng = np.random.default_rng(23)
+    n = 6000
+    mag = rng.uniform(2.0, 6.5, n)
+    ang = rng.uniform(-np.pi, np.pi, n)
+    h = np.zeros((n, 9))
+    h[:, 0], h[:, 1] = mag * np.cos(ang), -mag * np.sin(ang)
+    h[:, 3], h[:, 4] = mag * np.sin(ang), mag * np.cos(ang)
+    h[:, 2], h[:, 5] = rng.uniform(-2000, 2000, n), rng.uniform(-2000, 2000, n)
+    h[:, 6], h[:, 7] = rng.normal(0, 1e-5, n), rng.normal(0, 1e-5, n)
+    h[:, 8] = 1.0
+    h = h.astype(np.float32).astype(np.float64)
+    xb, yb = np.round(rng.uniform(0, 4000, n)), np.round(rng.uniform(0, 2000, n))
+    DX, DY = rng.integers(90, 128, n).astype(float), rng.integers(90, 128, n).astype(float)
+    rec, frac = check_cells(h, xb, yb, DX, DY, rng, samples=48)
+    reach = mag * np.hypot(DX, DY)                    # how far from the anchor a pixel of the cell can land
+    assert rec["good"][reach < 330].all(), "cells well inside the cap must keep their bound"
+    assert not rec["good"][mag * np.maximum(DX, DY) > 520].any(), "cells beyond the cap must take the exact path"
+    assert 0.2 < rec["good"].mean() < 0.9
+    print(f"near the limit: {rec['good'].mean():.3f} of the cells keep a bound, {frac:.2e} of their pixels in doubt")
+
+
 def test_cells_without_a_bound_flag_everything():
     """Denominator through zero inside the cell, non-finite entries, coordinates beyond 2^30, zero matrix."""
     rng = np.random.default_rng(2)
