@@ -1246,7 +1246,7 @@ def main():
             "equalize": {
                 "value": pair.shape[0] * pair.shape[1] * a.steps / t_eq / 1e6, "unit": "Mpix/s (rank 0)",
                 "ms_per_step": t_eq / a.steps * 1e3,
-                "roofline": {"kernels": "k_eq_hist (its last block builds the tables) + k_eq_apply", "bound": "hbm",
+                "roofline": {"kernels": "k_eq_hist + k_eq_apply", "bound": "hbm",
                              "achieved": 3.0 * pair.img.size / ((kern["eq_hist"] + kern["eq_apply"]) * 1e-3) / 1e9,
                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": 3.0 * pair.img.size / ((kern["eq_hist"] + kern["eq_apply"]) * 1e-3) / 1e9 / PEAK_HBM_GBS},
@@ -1256,7 +1256,7 @@ def main():
                 "ms_per_call": t_ransac / a.steps * 1e3, "hypotheses": N.RANSAC_ITERATIONS, "points": res.n,
                 "inliers": int(res.r_res.cpu()[1]),
                 "note": "device half of the seed homography (4-point hypotheses, 5 px), baseline_stitch_test.py:42; "
-                        "two small latency-bound launches (hypotheses; scoring, whose last block writes the winner out); extra, not in `value`"},
+                        "three small latency-bound kernels (fusing the selection into the scoring kernel's last block was measured in round 6: slower, profiles/r06_frontend_fusion.txt); extra, not in `value`"},
             "kernels_ms": kern,
             "roofline": {"kernel": "k_solve_small (fused K1 + K2: the K2 tail is inside the time, only K1's flops are counted)"
                                    if fused else "k_assemble_" + resolved, "bound": "mfma",

@@ -22,11 +22,10 @@ inline int hip_fail(hipError_t e, const char *what) { return apap::hip_fail((int
 // (1..4), so that phase is a per-lane constant and the channel of each of the lane's 48 bytes
 // selects one of C per-lane base addresses at compile time.
 // E1 k_eq_hist: per-wave private histograms in LDS (ds_add_u32), summed per block and added to
-//    one of kEqReplicas global histograms (same-address atomics limit a single one).  The block
-//    that finishes LAST sums the replicas, zeroes them again (the workspace contract: zero on
+//    one of kEqReplicas global histograms (same-address L2 atomics limit a single one).
+// E1b k_eq_lut: one block sums the replicas, zeroes them again (the workspace contract: zero on
 //    entry, zero on return - no memset per call) and builds the C x 256 lookup table (ballots
-//    and wave scans, all channels at once) - no launch of its own for 4 waves of work (round 6;
-//    "last" is decided without a fence, see last_block_done).
+//    and wave scans, all channels at once).
 // E2 k_eq_apply: maps every byte through the table (768 bytes in LDS, address formed by one
 //    v_perm_b32) and stores 1 KiB per instruction.
 // Algorithmic HBM traffic: 3 bytes per byte of image (read, read, write).
@@ -54,27 +53,6 @@ __device__ __forceinline__ EqSplit eq_split(const uint8_t *img, size_t bytes) {
     s.chunks = (bytes - s.head) / (kEqChunkVecs * 16);
     s.tail = s.head + s.chunks * (kEqChunkVecs * 16);
     return s;
-}
-
-// "Am I the last block of this launch to get here?" without a device-scope fence (on this 8-L2 part a __threadfence() in
-// every block took k_eq_hist from 9 to 76 us: round 1).  The blocks publish through RETURNING device-scope atomics only: such
-// an atomic is performed at the one place all eight XCDs share before its old value comes back, so once a thread holds the
-// return values (`seen`, forced into existence below) its updates are visible to any later atomic from anywhere.  The block
-// then takes a ticket - after a barrier, so after every thread's returns - whose operand carries a (vacuous) data dependence
-// on `seen`; the block that draws the last ticket knows that every other block's ticket, hence every other block's updates,
-// came first, and READS the shared words with returning atomics as well (atomicExch / atomicMax): no cached copy is involved
-// on either side.  Returns true in every thread of the last block.
-__device__ __forceinline__ bool last_block_done(unsigned int *ticket, unsigned int seen, unsigned int blocks) {
-    __shared__ bool s_last;
-    asm volatile("" : "+v"(seen));            // the returned values must have arrived: this thread's atomics are done
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int zero = 0;
-        asm volatile("" : "+v"(zero));        // opaque to the compiler: `seen & zero` stays an instruction
-        s_last = atomicAdd(ticket, 1u + (seen & zero)) == blocks - 1u;
-    }
-    __syncthreads();
-    return s_last;
 }
 
 // LDS byte address of a __shared__ object, and a byte load through such an address
@@ -149,7 +127,7 @@ __device__ void eq_build_luts(const unsigned int (&mine)[C], uint8_t *lut /* C x
 }
 
 template <int C>
-__global__ __launch_bounds__(kEqThreads) void k_eq_hist(const uint8_t *__restrict__ img, size_t bytes, int total,
+__global__ __launch_bounds__(kEqThreads) void k_eq_hist(const uint8_t *__restrict__ img, size_t bytes,
                                                         unsigned char *__restrict__ work) {
     __shared__ unsigned int h[kEqWaves][C * 256];
     unsigned int *hist = reinterpret_cast<unsigned int *>(work);
@@ -201,32 +179,38 @@ __global__ __launch_bounds__(kEqThreads) void k_eq_hist(const uint8_t *__restric
     }
     __syncthreads();
     unsigned int *replica = hist + (size_t)(blockIdx.x % kEqReplicas) * C * 256;
-    unsigned int seen = 0;
     for (int i = threadIdx.x; i < C * 256; i += kEqThreads) {
         unsigned int s = 0;
 #pragma unroll
         for (int w = 0; w < kEqWaves; ++w) s += h[w][i];
-        if (s) seen |= atomicAdd(&replica[i], s);
+        if (s) atomicAdd(&replica[i], s);
     }
-    unsigned int *ticket = reinterpret_cast<unsigned int *>(work + eq_ticket_offset(C));
-    if (!last_block_done(ticket, seen, gridDim.x)) return;
-    // the last block: the sum of the replicas (read and zeroed in one returning atomic each, all in flight together), the table
-    unsigned int v[C][kEqReplicas];
+}
+
+// E1b: one block sums the replicas, leaves them zeroed for the next call, and builds the table.
+// (Doing this in the last block of k_eq_hist to arrive needs a device-scope fence in every
+// block; on this 8-L2 part that fence took the kernel from 9 to 76 us.)
+template <int C>
+__global__ __launch_bounds__(kEqThreads) void k_eq_lut(int total, unsigned char *__restrict__ work) {
+    unsigned int *hist = reinterpret_cast<unsigned int *>(work);
+    unsigned int v[C][kEqReplicas];  // all C x kEqReplicas loads in flight together
 #pragma unroll
     for (int c = 0; c < C; ++c) {
 #pragma unroll
-        for (int r = 0; r < kEqReplicas; ++r) v[c][r] = atomicExch(&hist[(size_t)r * C * 256 + c * 256 + threadIdx.x], 0u);
+        for (int r = 0; r < kEqReplicas; ++r) v[c][r] = hist[(size_t)r * C * 256 + c * 256 + threadIdx.x];
     }
-    unsigned int bins[C];
+    unsigned int mine[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-        unsigned int sum = 0;
+        unsigned int s = 0;
 #pragma unroll
-        for (int r = 0; r < kEqReplicas; ++r) sum += v[c][r];
-        bins[c] = sum;
+        for (int r = 0; r < kEqReplicas; ++r) {
+            s += v[c][r];
+            hist[(size_t)r * C * 256 + c * 256 + threadIdx.x] = 0u;
+        }
+        mine[c] = s;
     }
-    if (threadIdx.x == 0) atomicExch(ticket, 0u);       // the next call starts from zero tickets
-    eq_build_luts<C>(bins, work + eq_lut_offset(C), total);
+    eq_build_luts<C>(mine, work + eq_lut_offset(C), total);
 }
 
 template <int C>
@@ -310,7 +294,8 @@ int launch_equalize(apap_ctx *ctx, const uint8_t *d_img, size_t bytes, int total
     const unsigned blocks = (unsigned)min((size_t)1024, (chunks + kEqWaves - 1) / kEqWaves);
     {
         apap::ProfScope prof(ctx, APAP_PROF_EQ_HIST, s);
-        hipLaunchKernelGGL(k_eq_hist<C>, dim3(blocks), dim3(kEqThreads), 0, s, d_img, bytes, total, work);
+        hipLaunchKernelGGL(k_eq_hist<C>, dim3(blocks), dim3(kEqThreads), 0, s, d_img, bytes, work);
+        hipLaunchKernelGGL(k_eq_lut<C>, dim3(1), dim3(kEqThreads), 0, s, total, work);
     }
     {
         apap::ProfScope prof(ctx, APAP_PROF_EQ_APPLY, s);
@@ -329,9 +314,8 @@ int launch_equalize(apap_ctx *ctx, const uint8_t *d_img, size_t bytes, int total
 //    elimination with partial pivoting on a lane-private 8 x 9 system kept in LDS (dynamic row
 //    indices; index-major layout, so the 64 lanes never conflict).  Products and differences are
 //    rounded separately (the library is built with -ffp-contract=off), as in the oracle.
-// R2 k_ransac_score: one block per hypothesis counts the points within the threshold and offers (count, index) to a 64-bit
-//    atomic maximum; the block that finishes last writes out the first hypothesis with the most inliers, its matrix and
-//    its mask (round 6: this tail was a launch of its own, k_ransac_select; last_block_done above).
+// R2 k_ransac_score: one block per hypothesis counts the points within the threshold.
+// R3 k_ransac_select: first hypothesis with the most inliers, its matrix and its mask.
 // A few thousand tiny solves and a few million point tests: launch-latency-bound, no roofline.
 // --------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -341,21 +325,14 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     return z ^ (z >> 31);
 }
 
-// hypotheses per block = active lanes of its one wave.  16 instead of 64 (round 6): 2048 hypotheses are 128 waves on 128 CUs
-// instead of 32 on 32, and every LDS access of the elimination is one pass of 16 lanes instead of four
-constexpr int kHypLanes = 16;
+constexpr int kHypLanes = 64;
 
 __global__ __launch_bounds__(kHypLanes) void k_ransac_hyp(const float *__restrict__ src, const float *__restrict__ dst,
                                                           int n, int iterations, unsigned long long seed,
-                                                          double *__restrict__ H /* iterations x 9 */,
-                                                          unsigned long long *__restrict__ vote /* key, ticket: zeroed here */) {
+                                                          double *__restrict__ H /* iterations x 9 */) {
     __shared__ double sys[72][kHypLanes];
     const int t = threadIdx.x;
     const int h = blockIdx.x * kHypLanes + t;
-    if (h == 0) {       // k_ransac_score's shared words start from zero (plain stores: the kernel boundary publishes them)
-        vote[0] = 0ull;
-        vote[1] = 0ull;
-    }
     if (h >= iterations) return;  // lane-private work below: no barriers
 #define A(r, c) sys[(r) * 9 + (c)][t]
     // four distinct indices: draw j is taken modulo n - j, then stepped over the earlier picks
@@ -435,8 +412,7 @@ __device__ __forceinline__ bool ransac_inlier(const double (&h)[9], double x, do
 
 __global__ __launch_bounds__(256) void k_ransac_score(const float *__restrict__ src, const float *__restrict__ dst, int n,
                                                       const double *__restrict__ H, double thr2,
-                                                      unsigned long long *__restrict__ vote, double *__restrict__ H_best,
-                                                      uint8_t *__restrict__ mask, int *__restrict__ result) {
+                                                      int *__restrict__ counts) {
     __shared__ int s_part[4];
     double h[9];
 #pragma unroll
@@ -451,25 +427,40 @@ __global__ __launch_bounds__(256) void k_ransac_score(const float *__restrict__ 
     for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
     __syncthreads();
-    // most inliers first, then the LOWEST hypothesis index: one unsigned 64-bit maximum
-    unsigned int seen = 0;
-    if (threadIdx.x == 0) {
-        const unsigned long long key = ((unsigned long long)(unsigned)(s_part[0] + s_part[1] + s_part[2] + s_part[3]) << 32) |
-                                       (unsigned long long)(0xffffffffu - blockIdx.x);
-        seen = (unsigned int)atomicMax(&vote[0], key);
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(256) void k_ransac_select(const float *__restrict__ src, const float *__restrict__ dst, int n,
+                                                       const double *__restrict__ H, const int *__restrict__ counts,
+                                                       int iterations, double thr2, double *__restrict__ H_best,
+                                                       uint8_t *__restrict__ mask, int *__restrict__ result) {
+    __shared__ int s_cnt[256], s_idx[256];
+    int bc = -1, bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < iterations; i += 256) {  // ascending: strictly greater keeps the first
+        const int c = counts[i];
+        if (c > bc) { bc = c; bi = i; }
     }
-    if (!last_block_done(reinterpret_cast<unsigned int *>(&vote[1]), seen, gridDim.x)) return;
-    // the last block: the winner, its matrix and its mask
-    __shared__ unsigned long long s_key;
-    if (threadIdx.x == 0) s_key = atomicMax(&vote[0], 0ull);
+    s_cnt[threadIdx.x] = bc;
+    s_idx[threadIdx.x] = bi;
     __syncthreads();
-    const unsigned int best = 0xffffffffu - (unsigned int)(s_key & 0xffffffffull);
+    for (int d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) {
+            const int oc = s_cnt[threadIdx.x + d], oi = s_idx[threadIdx.x + d];
+            if (oc > s_cnt[threadIdx.x] || (oc == s_cnt[threadIdx.x] && oi < s_idx[threadIdx.x])) {
+                s_cnt[threadIdx.x] = oc;
+                s_idx[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int best = s_idx[0];
+    double h[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) h[i] = H[(size_t)best * 9 + i];
     if (threadIdx.x < 9) H_best[threadIdx.x] = h[threadIdx.x];
     if (threadIdx.x == 0) {
-        result[0] = (int)best;
-        result[1] = (int)(s_key >> 32);
+        result[0] = best;
+        result[1] = s_cnt[0];
     }
     for (int k = threadIdx.x; k < n; k += 256) {
         const float2 s = reinterpret_cast<const float2 *>(src)[k];
@@ -484,7 +475,7 @@ extern "C" {
 
 size_t apap_ransac_workspace_bytes(int n, int iterations) {
     if (n < 4 || iterations < 1) return 0;
-    return (size_t)iterations * 9 * sizeof(double) + (size_t)(iterations < 4 ? 4 : iterations) * sizeof(int);   // matrices; vote key + ticket
+    return (size_t)iterations * 9 * sizeof(double) + (size_t)iterations * sizeof(int);
 }
 
 int apap_ransac_device(apap_ctx *ctx, const float *d_src, const float *d_dst, int n, double thresh, int iterations,
@@ -502,14 +493,16 @@ int apap_ransac_device(apap_ctx *ctx, const float *d_src, const float *d_dst, in
         return apap::fail(APAP_ERR_INVALID_ARG, "apap_ransac_device: points and workspace must be 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     double *H = (double *)d_work;
-    unsigned long long *vote = (unsigned long long *)(H + (size_t)iterations * 9);     // best (count, index) key; ticket
+    int *counts = (int *)(H + (size_t)iterations * 9);
     const double thr2 = thresh * thresh;
     {
         apap::ProfScope prof(ctx, APAP_PROF_RANSAC, s);
         hipLaunchKernelGGL(k_ransac_hyp, dim3((iterations + kHypLanes - 1) / kHypLanes), dim3(kHypLanes), 0, s, d_src,
-                           d_dst, n, iterations, seed, H, vote);
+                           d_dst, n, iterations, seed, H);
         hipLaunchKernelGGL(k_ransac_score, dim3(iterations), dim3(256), 0, s, d_src, d_dst, n, (const double *)H, thr2,
-                           vote, d_H_best, d_mask, d_result);
+                           counts);
+        hipLaunchKernelGGL(k_ransac_select, dim3(1), dim3(256), 0, s, d_src, d_dst, n, (const double *)H,
+                           (const int *)counts, iterations, thr2, d_H_best, d_mask, d_result);
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "apap_ransac_device launch");

@@ -464,12 +464,14 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         }
     };
     auto accumulate = [&](double w2, const unsigned char *at0, const unsigned char *at1) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, *reinterpret_cast<const double *>(at0), acc0, 0, 0, 0);
+        const double b0 = *reinterpret_cast<const double *>(at0);
+        const double b1 = *reinterpret_cast<const double *>(at1);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b0, acc0, 0, 0, 0);
         if constexpr (kM24) {
-            acc_a = __builtin_amdgcn_mfma_f64_4x4x4f64(w2, *reinterpret_cast<const double *>(at1), acc_a, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f64_4x4x4f64(w2, b1, acc_a, 0, 0, 0);
             acc_b = __builtin_amdgcn_mfma_f64_4x4x4f64(w2, *reinterpret_cast<const double *>(at1 + 32), acc_b, 0, 0, 0);
         } else {
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, *reinterpret_cast<const double *>(at1), acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, b1, acc1, 0, 0, 0);
         }
     };
     if (nchunks > 0) load_chunk(0);

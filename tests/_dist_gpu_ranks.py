@@ -39,6 +39,9 @@ def main():
     assert np.array_equal(H, H2) and s.overlap
     s_one = ShardedSolver(p, dev, dist, overlap=False)    # one launch + one gather per rank
     assert np.array_equal(s_one.solve().cpu().numpy(), H)
+    assert s_one._plan is None                            # a solve-only caller pays for no warp plan (made at the first warp / step)
+    s_one = ShardedSolver(p, dev, dist, overlap=False, resident_warp=True)
+    assert np.array_equal(s_one.solve().cpu().numpy(), H)
     s_bits = ShardedSolver(p, dev, dist, same_bits=True)  # the whole mesh's summation order on every shard
     H_bits = s_bits.solve().cpu().numpy().copy()
     band = s.warp(gather=False).cpu().numpy()             # the canvas left distributed: this rank's rows only

@@ -120,6 +120,9 @@ def test_single_process_sharded_solver_keeps_a_warp_plan(native):
     p = config_pair("C2")
     s = ShardedSolver(p, dev)
     H = s.solve().cpu().numpy().reshape(100, 100, 3, 3)
+    assert s._plan is None                  # a caller that only solves gets the plain K2 and no canvas-sized workspace
+    s = ShardedSolver(p, dev, resident_warp=True)
+    assert np.array_equal(s.solve().cpu().numpy().reshape(100, 100, 3, 3), H)
     assert s._plan is not None and s._cells_ready and s._aligned and s.bands == [(0, p.final_h)]
     ctx = native.Context(profile=1)
     try:

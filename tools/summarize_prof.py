@@ -18,8 +18,8 @@ def short(name):
     if "k_warp<true>" in name or "k_warpILb1E" in name:
         return "k_warp<stitch>"
     for k in ("k_assemble_valu", "k_assemble_mfma4", "k_assemble_mfma", "k_solve_small", "k_eigen_denorm", "k_invert_cells", "k_cell_lut", "k_warp_coords",
-              "k_warp_setup", "k_warp_fast", "k_warp", "k_flatten", "k_weights", "k_blend", "k_eq_hist", "k_eq_apply",
-              "k_ransac_hyp", "k_ransac_score"):
+              "k_warp_setup", "k_warp_fast", "k_warp", "k_flatten", "k_weights", "k_blend", "k_eq_hist", "k_eq_lut", "k_eq_apply",
+              "k_ransac_hyp", "k_ransac_score", "k_ransac_select"):
         if k in name:
             return k
     return None
