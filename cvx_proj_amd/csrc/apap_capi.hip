@@ -237,7 +237,7 @@ int apap_local_homography_pts(apap_ctx *ctx, const void *src, int src_f64, const
 // buffer by the kernel instead of a DMA copy), so what the overlap hides is the kernels, the set-up and the
 // per-copy latencies, not half of the bytes.  And pinning is not free: the FIRST call on a buffer (a new virtual range)
 // spends ~1 ms registering it and ~7 ms at its first DMA use; only later calls on the same buffers run at 0.93 ms
-// (tools/pipe_trace.py).  Hence opt-in (APAP_OPT_OVERLAP_PCIE = 1): right for a caller that streams pairs through buffers it
+// (profiles/r03_pcie_overlap.txt).  Hence opt-in (APAP_OPT_OVERLAP_PCIE = 1): right for a caller that streams pairs through buffers it
 // keeps, wrong for one warp into a fresh array - the default stays the plain sequence.
 // WHICH source rows a band can read is not guessed: the set-up kernel reports, per cell row, an interval that
 // contains the source row of every pixel of every cell in it (anchor row -+ the bound of the float32
@@ -333,7 +333,7 @@ int warp_overlapped(apap_ctx *ctx, apap_ctx *pool, int dev, const uint8_t *img, 
     // Only the three big buffers are pinned, and only when no two of them share a page.  History: with the grid and its
     // inverse pinned as well (numpy's `H.copy()` followed by `np.empty_like(H)`: back to back) one run of round 3 ended in a
     // GPU fault "write access to a read-only page", attributed then to the two registrations sharing a page.  Round 4's
-    // stand-alone reproducer of exactly that layout (tools/hostreg_pages.hip, profiles/r04_hostreg_pages.txt: both ranges
+    // stand-alone reproducer of exactly that layout (profiles/r04_hostreg_pages.txt, the program at git tag r05-hooks: both ranges
     // registered, DMA in both directions and at once, a kernel reading one and writing the other through the device
     // pointers, either unregistration order) runs clean on this stack: the shared page was NOT the cause, which stays
     // unknown (no log of the fault survived).  The rule is kept because it costs nothing: pinning 1.4 MB buys nothing (the

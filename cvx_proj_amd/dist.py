@@ -246,7 +246,7 @@ class ShardedSolver:
     With ``overlap=True`` the rank's rows are solved in TWO launches and the first half's all-gather runs while
     the second half is being computed.  What that buys depends on what bounds the collective: the second gather is
     exposed either way, so a latency-bound gather gains nothing and the split costs its launch overhead - measured on
-    one GPU playing a rank of C4 (``tools/shard_solve_cost.py``): +11 us at 2 ranks (715 -> 726 us), +15 at 4,
+    one GPU playing a rank of C4 (``tools/scaling_model.py``; round 3: tools/shard_solve_cost.py at git tag r05-hooks): +11 us at 2 ranks (715 -> 726 us), +15 at 4,
     +24 at 8 (189 -> 213 us).  The H grid is 36 B per cell: at 2 ranks a rank receives 2.9 MB over one xGMI link
     (bandwidth-bound, ~60 us: hiding half of it pays), at 8 ranks 720 KB over each of 7 links (~15 us of wire time
     under ~20 us of latency: it does not).  ``overlap="auto"`` (default) therefore splits for world sizes up to 4.

@@ -156,7 +156,7 @@ class Pipeline:
         and the host set-up, the small uploads and the solve run beside it: every copy of such a pass is a page-locked one -
         keypoint table and de-normalisation are built straight into a staging block, the ``.mat`` array and the status word come
         down into staging - because ONE pageable copy on the side stream makes the small uploads of every later pass wait for
-        the whole image upload (measured: tools/torch_copy_overlap.py, profiles/r04_pipeline_overlap.txt; 1.33 -> 1.04 ms).
+        the whole image upload (measured: profiles/r04_pipeline_overlap.txt; its script at git tag r05-hooks; 1.33 -> 1.04 ms).
         The solve's tail leaves every cell warp ready, so the warp is the gather kernel alone on tables whose geometry half
         (and the mesh's vertices) were built when this canvas geometry was first seen; the canvas download is the one copy
         left on the critical path (0.5 ms of the 1.04).  ``self.trace = True`` records HIP events at the stage boundaries
@@ -205,7 +205,7 @@ class Pipeline:
         q = _native.host_prepare(src, dst)                                  # apap.py:132-140 in C
         # keypoint table and de-normalisation written straight into ONE page-locked staging block: a single asynchronous copy.
         # (A copy from pageable memory, however small, queues behind the 25 MB image copy in the runtime: measured 350 us of
-        # waiting, the solve starting when the upload had finished - tools/pipeline_order.py, profiles/r04_pipeline_overlap.txt.)
+        # waiting, the solve starting when the upload had finished - profiles/r04_pipeline_overlap.txt.)
         n = int(np.asarray(src).shape[0])
         nt, nd = n * _native.TABLE_STRIDE, _native.DENORM_DOUBLES
         stage = self._staging(nt + nd)
@@ -287,7 +287,7 @@ class Pipeline:
                 if pinned_in:
                     # page-locked staging, copied into the result while the canvas comes down.  NOT a copy into pageable memory:
                     # one pageable copy on the side stream and, from the next pass on, the small uploads on the main stream wait
-                    # for the whole image upload on the side stream (tools/torch_copy_overlap.py: 476 instead of 55 us)
+                    # for the whole image upload on the side stream (476 instead of 55 us, profiles/r04_pipeline_overlap.txt)
                     if getattr(self, "_flat_host", None) is None or self._flat_host.numel() < cells * 9:
                         self._flat_host = torch.empty(cells * 9, dtype=torch.float64, pin_memory=True)
                     self._flat_host[:cells * 9].copy_(d_flat.view(-1), non_blocking=True)

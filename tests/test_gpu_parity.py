@@ -1004,7 +1004,7 @@ def test_overlapped_host_warp_equals_sequential(native, golden):
 
 def test_overlapped_host_warp_on_buffers_that_share_pages(native, golden):
     """Round 3 saw one GPU fault ("write access to a read-only page") with the grid and its inverse pinned next to each other;
-    tools/hostreg_pages.hip (profiles/r04_hostreg_pages.txt) runs that layout - two registrations sharing a page, DMA and
+    A stand-alone HIP program (profiles/r04_hostreg_pages.txt; source at git tag r05-hooks) runs that layout - two registrations sharing a page, DMA and
     kernel access, either unregistration order - without a fault, so the cause was not the shared page; the call still pins
     only page-disjoint big buffers.  Here every buffer of the call is a view of ONE allocation, neighbours 16 bytes apart
     (source image, canvas, centre image, the grid and the array its inverses are written back to - numpy's H.copy() followed by

@@ -1,6 +1,8 @@
 #!/bin/bash
-# A/B of experimental BUILDS of the library on ONE box: every tools/variants/lib_*.so (built here with
-# extra -D flags, e.g. -DAPAP_K1_GROUP=4; *.so travel to the GPU box, they are only git-ignored) against
+# A/B of experimental BUILDS of the library on ONE box: every tools/variants/lib_*.so (built from a modified
+# copy of cvx_proj_amd/csrc - the product sources carry no tuning switches since round 6 -, e.g.
+#   make -C /path/to/copy/csrc OUT=$PWD/tools/variants/lib_try.so
+# ; tools/variants/ is git-ignored AND gpurun-ignored: build on the GPU box, in the same call) against
 # the in-tree library, ROUNDS alternating passes.  The working library is never overwritten: the
 # binding loads $APAP_HIP_LIB.   tools/ab_build.sh [config]
 CFG=${1:-C3}

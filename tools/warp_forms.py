@@ -67,7 +67,7 @@ def main():
         torch.cuda.synchronize()
         if ref is None:
             ref = outs[0].clone()
-        timing_only = os.environ.get("APAP_AB_TIMING_ONLY") == "1"      # ablation builds (tools/ab_forms.sh): wrong pixels on purpose
+        timing_only = os.environ.get("APAP_AB_TIMING_ONLY") == "1"      # a build under test that gives wrong pixels on purpose (ablations)
         assert timing_only or torch.equal(outs[0], ref), f"{form}: canvas differs from the first form's"
         res = {"config": a.config, "form": form, "rows": a.rows or p.final_h}
         for mode, n in (("warm", 1), ("cold", nsets)):
