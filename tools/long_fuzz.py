@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import contextlib
 import io
 
+import torch  # noqa: F401  (before the library is loaded: one HIP runtime per process, cvx_proj_amd/_native.py)
 import test_gpu_fuzz as T
 from cvx_proj_amd import _native
 
