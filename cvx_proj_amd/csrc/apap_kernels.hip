@@ -281,7 +281,7 @@ __device__ __forceinline__ double cell_weight_sq_tab(double vx, double vy, doubl
 
 // w^2 in float32 for the opt-in tolerance tier (APAP_OPT_WEIGHTS_F32 with APAP_OPT_MOMENTS = 24): v_sqrt_f32 and
 // v_exp_f32 (1 ulp each), 9 vector instructions instead of 24.  w^2 carries ~2e-7 relative error: the float32 grid moves by
-// at most one ulp in a few per cent of its entries (tools/moments24_study.py), like the 24-sum table itself.
+// at most one ulp in a few per cent of its entries (tests/studies/moments24_study.py), like the 24-sum table itself.
 //   neg_scale = -2 log2(e) / sigma^2;  NaN coordinates give gamma^2 (v_max_f32 drops the NaN), as in the float64 chain
 __device__ __forceinline__ double cell_weight_sq_f32(float vx, float vy, float2 s, float neg_scale, float gamma2) {
     const float dx = vx - s.x;

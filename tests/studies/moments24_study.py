@@ -3,7 +3,7 @@ the normal matrix is built from the 24 exact-product sums instead of the 30 sums
 float32-rounded products, and when the weights are evaluated in float32.  Test infrastructure (imports oracle/)."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")      # run from the repository root: python tests/studies/moments24_study.py
 from oracle import apap_oracle as O
 from cvx_proj_amd.synth import config_pair
 

@@ -18,7 +18,7 @@ from conftest import ulp_diff_f32
 pytestmark = pytest.mark.gpu
 RMSE_BAR = 1e-4          # px, north_star: met by the default only (see above)
 ONE_ULP_CLASS = 1.5e-3   # px: what one float32 ulp of a grid entry can move a keypoint of an 8K image by
-MAX_ULP = 1              # measured: 1 (tools/moments24_study.py, profiles/r06_k1_modes_C3.txt)
+MAX_ULP = 1              # measured: 1 (tests/studies/moments24_study.py, profiles/r06_k1_modes_C3.txt)
 MAX_FRACTION = 0.08      # of a grid's float32 values; measured 0.3-3 %
 
 
