@@ -2,7 +2,7 @@
 """How far do normal-equation solvers (the GPU engine, and numpy eigh) stray from the reference's
 SVD of the weighted 2n x 9 system when it is barely determined (n = 5..12)?"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import apap_oracle as O
 from cvx_proj_amd import _native as N
