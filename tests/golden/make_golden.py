@@ -22,6 +22,8 @@ script is how they were made.
     C5          eight of the 64 independent pairs (pairs 0, 1 in full, 2..7 every 4th mesh row + SHA-256 of the grid)
     C5warp      c5_warp_k0 / c5_warp_k1: the reference's local_warp canvas of C5 pairs 0 and 1 (100 x 100 mesh over a 4K
                 canvas; SHA-256 + every 64th row) and the SHA-256 of the in-place inverses (~1 min each)
+    C5all       c5_all_sha: ALL 64 pairs of config 5 through the reference's local_homography AND local_warp, in a process pool
+                (~1 minute of the reference's loops per pair): SHA-256 of every grid, of its in-place inverses and of every canvas
     f64pts      f64pts_ref: keypoints that are not float32 arrays (float64, one float64 set beside a float32 one, int64)
                 through the reference as it is: every intermediate of the set-up and the H grids
     illcond     illcond_ref: the six soak seeds of round 1 whose weighted systems are numerically rank-deficient
@@ -430,7 +432,47 @@ def keypoints_case(name="keypoints_ref.npz"):
     print(f"{name}: get_features for pictures 1, 2, 4, 5")
 
 
+_POOL = {}
+
+
+def _c5_pool_init():
+    os.environ["OPENBLAS_NUM_THREADS"] = "1"
+    _POOL["ref"] = import_reference()
+
+
+def _c5_pair(k):
+    """One pair of config 5 (seed 6400 + k) through the reference: grid, in-place inverses, canvas - as SHA-256 digests."""
+    ref_apap, ref_utils = _POOL["ref"]
+    sys.path.insert(0, REPO)
+    from cvx_proj_amd.synth import config_pair
+    p = config_pair("C5", with_image=True, seed_offset=k)
+    fw, fh, ox, oy = ref_utils.final_size(Shape(p.shape), Shape(p.shape), p.Hg)
+    assert (fw, fh, ox, oy) == (p.final_w, p.final_h, p.off_x, p.off_y)
+    eng = ref_apap.APAP(p.gamma, p.sigma, [fw, fh], [ox, oy])
+    H_ref, _ = eng.local_homography(p.src, p.dst, p.vertices)
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)  # noqa: E731
+    h = sha(H_ref)
+    H_arg = H_ref.copy()
+    warped = eng.local_warp(p.img, H_arg, p.mesh, False)
+    return k, h, sha(H_arg), sha(warped), np.array([fw, fh, ox, oy], dtype=np.int64)
+
+
+def c5_all(name="c5_all_sha.npz", pairs=64, workers=None):
+    import multiprocessing as mp
+    workers = workers or max(1, (os.cpu_count() or 2) - 0)
+    with mp.get_context("spawn").Pool(workers, initializer=_c5_pool_init) as pool:
+        res = sorted(pool.imap_unordered(_c5_pair, range(pairs)), key=lambda r: r[0])
+    assert [r[0] for r in res] == list(range(pairs)) and all(np.array_equal(r[4], res[0][4]) for r in res)
+    np.savez_compressed(os.path.join(HERE, name), H_sha256=np.stack([r[1] for r in res]), Hinv_sha256=np.stack([r[2] for r in res]),
+                        warped_sha256=np.stack([r[3] for r in res]), final=res[0][4])
+    print(f"{name}: {pairs} pairs of C5, canvas {tuple(res[0][4])}")
+
+
 def main():
+    if "C5all" in sys.argv[1:]:
+        c5_all()
+        if len(sys.argv) == 2:
+            return
     ref_apap, ref_utils = import_reference()
     which = sys.argv[1:] or ["tiny", "keypoints", "edge", "prepare", "C1", "C2"]
     if "keypoints" in which:

@@ -92,6 +92,35 @@ def test_c5_batched_warp_vs_reference(native, golden):
         assert torch.equal(out[k], canv[k])
 
 
+def test_all_64_pairs_of_config_5_vs_reference(native, golden):
+    """BASELINE config 5 in full: every one of the 64 independent 4K pairs solved (batched launches) and warped (batched
+    launches) - the float32 grid, the in-place inverses the reference leaves in its argument (apap.py:201-203) and the canvas of
+    EACH pair against the reference's own loops (tests/golden/c5_all_sha.npz, make_golden.py C5all: ~1 minute of the reference
+    per pair), by SHA-256."""
+    import torch
+    from cvx_proj_amd.dist import hip_warp_batch, solve_pairs
+    g = golden("c5_all_sha")
+    assert g["H_sha256"].shape == (64, 32)
+    dev = torch.device("cuda:0")
+    for lo in range(0, 64, 16):         # sixteen pairs at a time: 25 MB of image and 27 MB of canvas per pair
+        pairs = [config_pair("C5", seed_offset=k) for k in range(lo, lo + 16)]
+        p0 = pairs[0]
+        assert (p0.final_w, p0.final_h, p0.off_x, p0.off_y) == tuple(int(v) for v in g["final"])
+        grids = solve_pairs(pairs, dev)
+        for i, H in enumerate(grids):
+            assert sha(H) == g["H_sha256"][lo + i].tobytes(), f"grid of pair {lo + i} differs from the reference's"
+        H = torch.stack([torch.from_numpy(x.reshape(-1, 9)) for x in grids]).to(dev)
+        imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)
+        mw, mh = torch.from_numpy(p0.mesh[0].copy()).to(dev), torch.from_numpy(p0.mesh[1].copy()).to(dev)
+        hinv_out = torch.zeros_like(H)
+        out, st = hip_warp_batch(imgs, H, mw, mh, p0.final_w, p0.final_h, p0.off_x, p0.off_y, (100, 100), hinv_out=hinv_out)
+        assert int(st.cpu()[0]) == 0
+        for i in range(16):
+            assert sha(hinv_out[i].cpu().numpy().reshape(100, 100, 3, 3)) == g["Hinv_sha256"][lo + i].tobytes(), lo + i
+            assert sha(out[i].cpu().numpy()) == g["warped_sha256"][lo + i].tobytes(), f"canvas of pair {lo + i} differs from the reference's"
+        del pairs, imgs, out, H, hinv_out
+
+
 @pytest.mark.parametrize("rows_per_wave,fast", [(1, 1), (4, 1), (2, 1), (5, 1), (6, 1), (8, 1), (4, 0), (0, 1)])
 def test_batched_warp_equals_per_pair_launches(native, rows_per_wave, fast):
     """Every kernel form (float32-estimate strips, all-float64 strips, flat order) with grid.z = pair: the canvases
