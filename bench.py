@@ -33,7 +33,9 @@ cells configuration's canvas and ``pairs.warp.roofline`` for the batched warp of
 (the solve and the warp as calls of their own, without the warp-ready tail / with the set-up launch);
 ``call_level`` (numpy in -> numpy out through the host-buffer entry points: host set-up, PCIe and
 synchronisation included); ``pipeline`` (apap.py's __main__ as one resident pass: from ordinary numpy
-arrays, from page-locked ones, and as the reference's chain of calls) and ``cpu_baseline`` (the oracle's
+arrays, from page-locked ones, and as the reference's chain of calls); ``cli`` (fresh-process wall time of the drop-in command, one
+pair and sixteen); ``configs`` (BASELINE's other single-GPU configurations, C1 and C2, on the headline's definitions); ``moments24``
+(the opt-in 24-sum solve forms beside the default, with how far their grids are from it) and ``cpu_baseline`` (the oracle's
 faithful-loop numpy port on this host: 1 thread, default BLAS threads, all usable cores).
 
 Multi-rank runs: a 120 s collective timeout, a tiny first collective and a phase marker on stderr before
@@ -556,6 +558,36 @@ def pipeline_level(cfg, reps=5):
                     "caller keeps its image and canvas in Pipeline.pinned_array() buffers (every copy of the pass page-locked and asynchronous: "
                     "the image upload runs beside the host set-up, the small uploads and the solve; device_marks = HIP events at the "
                     "stage boundaries of one such pass, microseconds from its first enqueue); never `value`"}
+
+
+def cli_level(cfg="C1", reps=3):
+    """Wall time of the drop-in command in a FRESH process (python -m cvx_proj_amd.apap 1 1 --synth C1: interpreter, numpy, the HIP
+    runtime coming up, the first launch with its code-object load, one pair, savemat) - what the reference's one-process-per-pair
+    driver (run_all.sh) pays per pair - and of 16 pairs in one process (--cases 1-4 --imgs 1,2,4,5).  Children of this process
+    (never exec)."""
+    import tempfile
+
+    def run(args):
+        with tempfile.TemporaryDirectory() as tmp:
+            cmd = [sys.executable, "-m", "cvx_proj_amd.apap"] + args + ["--out-prefix", tmp + "/", "--timing"]
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
+            wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-500:])
+        return wall, json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{")][-1])
+    try:
+        one = min((run(["1", "1", "--synth", cfg]) for _ in range(reps)), key=lambda x: x[0])
+        loop = min((run(["--cases", "1-4", "--imgs", "1,2,4,5", "--synth", cfg]) for _ in range(reps)), key=lambda x: x[0])
+    except Exception as e:      # noqa: BLE001  (never take the GPU numbers down)
+        return {"error": repr(e)[:300]}
+    st = one[1]
+    return {"workload": f"{cfg}, fresh process: python -m cvx_proj_amd.apap 1 1 --synth {cfg}", "wall_ms": one[0] * 1e3,
+            "interpreter_and_numpy_ms": one[0] * 1e3 - st["total_ms"], "runtime_init_ms": st["runtime_init_ms"],
+            "first_pair_compute_ms": st["pairs"][0]["compute_ms"], "savemat_ms": st["pairs"][0]["save_ms"],
+            "sixteen_pairs_one_process_wall_ms": loop[0] * 1e3, "later_pair_compute_ms": loop[1]["pairs"][-1]["compute_ms"],
+            "note": "min of %d fresh processes; no torch in them (rounds 1-5 imported it: 1.39 s, profiles/r06_cli.txt).  Not part "
+                    "of `value`" % reps}
 
 
 # ------------------------------------------------------------------------------------ self-launch
@@ -1305,6 +1337,7 @@ def main():
         if world == 1 and not a.no_call_level:
             line["call_level"] = call_level(a.config)
             line["pipeline"] = pipeline_level(a.config)
+            line["cli"] = cli_level()
         if world == 1 and not a.no_cpu_baseline:
             workers = usable_cores() if a.cpu_pool < 0 else a.cpu_pool
             line["cpu_baseline"] = cpu_baseline(a.config, a.cpu_cells, a.cpu_rows, min(workers, 256))
