@@ -25,6 +25,8 @@ script is how they were made.
     C5odd       c5_ref_k8 / c5_ref_k49: the reference's full grids of the two C5 pairs on which the engine's grid differs from it in
                 one float32 value by one ulp (in one of them the REFERENCE's float64 SVD is the one that is off: a 60-digit SVD agrees
                 with the engine)
+    C3seeds     c3_seeds_sha: sixteen pairs of the headline configuration (seed offsets 0..15) through the reference's
+                local_homography and local_warp, in a process pool: SHA-256 of every grid, its in-place inverses and its canvas
     C5all       c5_all_sha: ALL 64 pairs of config 5 through the reference's local_homography AND local_warp, in a process pool
                 (~1 minute of the reference's loops per pair): SHA-256 of every grid, of its in-place inverses and of every canvas
     f64pts      f64pts_ref: keypoints that are not float32 arrays (float64, one float64 set beside a float32 one, int64)
@@ -444,11 +446,16 @@ def _c5_pool_init():
 
 
 def _c5_pair(k):
-    """One pair of config 5 (seed 6400 + k) through the reference: grid, in-place inverses, canvas - as SHA-256 digests."""
+    return _cfg_pair(("C5", k))
+
+
+def _cfg_pair(job):
+    """One pair of a config (its seed + k) through the reference: grid, in-place inverses, canvas - as SHA-256 digests."""
+    cfg, k = job
     ref_apap, ref_utils = _POOL["ref"]
     sys.path.insert(0, REPO)
     from cvx_proj_amd.synth import config_pair
-    p = config_pair("C5", with_image=True, seed_offset=k)
+    p = config_pair(cfg, with_image=True, seed_offset=k)
     fw, fh, ox, oy = ref_utils.final_size(Shape(p.shape), Shape(p.shape), p.Hg)
     assert (fw, fh, ox, oy) == (p.final_w, p.final_h, p.off_x, p.off_y)
     eng = ref_apap.APAP(p.gamma, p.sigma, [fw, fh], [ox, oy])
@@ -471,7 +478,24 @@ def c5_all(name="c5_all_sha.npz", pairs=64, workers=None):
     print(f"{name}: {pairs} pairs of C5, canvas {tuple(res[0][4])}")
 
 
+def seeds_all(cfg, name, pairs, workers=None):
+    """`pairs` pairs of `cfg` with seed offsets 0 .. pairs - 1 (offset 0 = the config's own pair) through the reference."""
+    import multiprocessing as mp
+    workers = workers or max(1, os.cpu_count() or 2)
+    with mp.get_context("spawn").Pool(workers, initializer=_c5_pool_init) as pool:
+        res = sorted(pool.imap_unordered(_cfg_pair, [(cfg, k) for k in range(pairs)]), key=lambda r: r[0])
+    np.savez_compressed(os.path.join(HERE, name), H_sha256=np.stack([r[1] for r in res]), Hinv_sha256=np.stack([r[2] for r in res]),
+                        warped_sha256=np.stack([r[3] for r in res]), final=res[0][4])
+    print(f"{name}: {pairs} pairs of {cfg}, canvas {tuple(res[0][4])}")
+
+
 def main():
+    if "C3seeds" in sys.argv[1:]:
+        # sixteen 4K pairs at the headline configuration (seed offsets 0..15; offset 0 is c3_ref's pair): ~1.5 minutes of the
+        # reference's loops each
+        seeds_all("C3", "c3_seeds_sha.npz", 16)
+        if len(sys.argv) == 2:
+            return
     if "C5all" in sys.argv[1:]:
         c5_all()
         if len(sys.argv) == 2:

@@ -147,6 +147,31 @@ def test_all_64_pairs_of_config_5_vs_reference(native, golden):
     assert len(odd) <= len(C5_ONE_ULP_PAIRS)
 
 
+C3_ONE_ULP_SEEDS = {}        # seed offset -> why (none found in round 6)
+
+
+def test_sixteen_pairs_of_the_headline_configuration_vs_reference(native, golden):
+    """Sixteen 4K pairs at the headline configuration (C3 with seed offsets 0..15: 2000 keypoints, 200 x 200 mesh) through the
+    host-buffer entry points: the float32 grid, the in-place inverses and the canvas of each against the reference's own loops
+    (tests/golden/c3_seeds_sha.npz, make_golden.py C3seeds), by SHA-256 - 5.76 million more float32 values behind the observed
+    rate of test_all_64_pairs_of_config_5_vs_reference."""
+    g = golden("c3_seeds_sha")
+    n = g["H_sha256"].shape[0]
+    odd = []
+    for k in range(n):
+        p = config_pair("C3", seed_offset=k)
+        assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
+        H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+        if sha(H) != g["H_sha256"][k].tobytes():
+            odd.append(k)
+            continue            # (no reference grid to warp from: the grid's own fixture comes first, make_golden.py)
+        warped, hinv = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+        assert sha(hinv) == g["Hinv_sha256"][k].tobytes(), k
+        assert sha(warped) == g["warped_sha256"][k].tobytes(), f"canvas of pair {k} differs from the reference's"
+    print(f"[C3 seeds] {n - len(odd)} of {n} grids bit-identical to the reference's; others: {odd}")
+    assert set(odd) <= set(C3_ONE_ULP_SEEDS), f"grids of seed offsets {odd} differ from the reference's: run tests/studies on them"
+
+
 @pytest.mark.parametrize("rows_per_wave,fast", [(1, 1), (4, 1), (2, 1), (5, 1), (6, 1), (8, 1), (4, 0), (0, 1)])
 def test_batched_warp_equals_per_pair_launches(native, rows_per_wave, fast):
     """Every kernel form (float32-estimate strips, all-float64 strips, flat order) with grid.z = pair: the canvases
