@@ -22,9 +22,6 @@ script is how they were made.
     C5          eight of the 64 independent pairs (pairs 0, 1 in full, 2..7 every 4th mesh row + SHA-256 of the grid)
     C5warp      c5_warp_k0 / c5_warp_k1: the reference's local_warp canvas of C5 pairs 0 and 1 (100 x 100 mesh over a 4K
                 canvas; SHA-256 + every 64th row) and the SHA-256 of the in-place inverses (~1 min each)
-    C5odd       c5_ref_k8 / c5_ref_k49: the reference's full grids of the two C5 pairs on which the engine's grid differs from it in
-                one float32 value by one ulp (in one of them the REFERENCE's float64 SVD is the one that is off: a 60-digit SVD agrees
-                with the engine)
     C3seeds     c3_seeds_sha: sixteen pairs of the headline configuration (seed offsets 0..15) through the reference's
                 local_homography and local_warp, in a process pool: SHA-256 of every grid, its in-place inverses and its canvas
     C5all       c5_all_sha: ALL 64 pairs of config 5 through the reference's local_homography AND local_warp, in a process pool
@@ -533,11 +530,6 @@ def main():
         for k in range(8):
             config_case(ref_apap, ref_utils, "C5", f"c5_ref_k{k}.npz", warp_rows_every=0, seed_offset=k,
                         keep_rows_every=1 if k < 2 else 4)
-    if "C5odd" in which:
-        # the two pairs of the 64 whose engine grid is ONE float32 value (one ulp) away from the reference's (round 6,
-        # tests/studies/c5_mismatch.py): the reference's full grid, so that the tests can say exactly how far
-        for k in (8, 49):
-            config_case(ref_apap, ref_utils, "C5", f"c5_ref_k{k}.npz", warp_rows_every=0, seed_offset=k, keep_rows_every=1)
     if "C5warp" in which:
         # the warp half of config 5: the reference's pixel loop on pairs 0 and 1 (the image of pair k is drawn from seed 6400 + k)
         for k in range(2):

@@ -92,8 +92,31 @@ def test_c5_batched_warp_vs_reference(native, golden):
         assert torch.equal(out[k], canv[k])
 
 
-C5_ONE_ULP_PAIRS = {8: "the engine's float64 rounding (the reference's value is the exact answer's float32)",
-                    49: "the reference's float64 SVD (the engine's value is the exact answer's float32: 60-digit SVD)"}
+def reconcile(golden, cfg, k, H, want_sha, pts):
+    """The engine's grid of pair (cfg, k) against the reference's SHA-256.  Where they differ, tests/golden/one_ulp_cases.npz
+    (tests/studies/grid_mismatch.py) must hold the position: the REFERENCE's float32 value there and the exact answer's (a
+    60-digit SVD of the reference's own matrix).  The engine's value must be one ulp from the reference's, and the grid with the
+    reference's value patched in must hash to the reference's SHA-256 - every other value is then bit for bit.  Returns the
+    reference's grid and the number of patched values."""
+    if sha(H) == want_sha:
+        return H, 0
+    f = golden("one_ulp_cases")
+    rows = [n for n in range(len(f["seed"])) if str(f["cfg"][n]) == cfg and int(f["seed"][n]) == k]
+    assert rows, f"grid of {cfg} pair {k} differs from the reference's at a position no fixture names (tests/studies/grid_mismatch.py)"
+    P = H.copy()
+    for n in rows:
+        pos = (int(f["i"][n]), int(f["j"][n]), int(f["a"][n]), int(f["b"][n]))
+        mine, ref, exact = H[pos], f["reference"][n], f["exact"][n]
+        ulp = abs(int(np.float32(mine).view(np.int32)) - int(np.float32(ref).view(np.int32)))
+        who = "the engine has the exact answer's float32, the reference's float64 SVD is off" if mine == exact else \
+              "the reference has the exact answer's float32, the engine's float64 rounding is off" if ref == exact else "neither is exact"
+        print(f"[{cfg} pair {k}] cell {pos[:2]} entry {pos[2:]}: engine {mine!r}, reference {ref!r}, 60-digit SVD {exact!r}: {ulp} ulp - {who}")
+        assert ulp <= 1
+        P[pos] = ref
+    assert sha(P) == want_sha, f"{cfg} pair {k}: more values differ from the reference's grid than the fixture names"
+    d = O.reprojection_rmse_delta(H, P, pts).max()
+    assert d < 1e-4, d
+    return P, len(rows)
 
 
 def test_all_64_pairs_of_config_5_vs_reference(native, golden):
@@ -103,37 +126,24 @@ def test_all_64_pairs_of_config_5_vs_reference(native, golden):
     per pair), by SHA-256.
 
     What "bit-identical" means, measured over these 5.76 million float32 values: 62 grids equal the reference's bit for bit;
-    in pairs 8 and 49 ONE value of 90 000 differs by one ulp (tests/studies/c5_mismatch.py: in pair 8 the engine's float64
-    rounding crosses a float32 boundary, in pair 49 the REFERENCE's float64 LAPACK SVD does - a 60-digit SVD of the reference's
-    own matrix gives the engine's value).  Reprojection-RMSE delta 1.2e-6 and 3.8e-6 px: inside north_star's 1e-4 px.  The
-    reference's full grids of those two pairs are fixtures (c5_ref_k8 / k49); the warp of EVERY pair is checked from the
-    reference's grid, so that the canvases and inverses are compared on equal inputs."""
+    in pairs 8 and 49 ONE value of 90 000 differs by one ulp (`reconcile`: in pair 8 the engine's float64 rounding crosses a
+    float32 boundary, in pair 49 the REFERENCE's float64 LAPACK SVD does - a 60-digit SVD of the reference's own matrix gives the
+    engine's value).  Reprojection-RMSE delta 1.2e-6 and 3.8e-6 px: inside north_star's 1e-4 px.  The warp of every pair starts
+    from the reference's grid, so that canvases and inverses are compared on equal inputs."""
     import torch
     from cvx_proj_amd.dist import hip_warp_batch, solve_pairs
     g = golden("c5_all_sha")
     assert g["H_sha256"].shape == (64, 32)
     dev = torch.device("cuda:0")
-    odd = []
+    patched = 0
     for lo in range(0, 64, 16):         # sixteen pairs at a time: 25 MB of image and 27 MB of canvas per pair
         pairs = [config_pair("C5", seed_offset=k) for k in range(lo, lo + 16)]
         p0 = pairs[0]
         assert (p0.final_w, p0.final_h, p0.off_x, p0.off_y) == tuple(int(v) for v in g["final"])
         grids = solve_pairs(pairs, dev)
-        for i, H in enumerate(grids):
-            k = lo + i
-            if sha(H) == g["H_sha256"][k].tobytes():
-                continue
-            assert k in C5_ONE_ULP_PAIRS, f"grid of pair {k} differs from the reference's (no full reference grid to say by how much: " \
-                                          f"add it with make_golden.py C5odd)"
-            H_ref = golden(f"c5_ref_k{k}")["H_ref"]
-            assert sha(H_ref) == g["H_sha256"][k].tobytes()
-            differ = int((H != H_ref).sum())
-            ulp = int(np.abs(H.view(np.int32).astype(np.int64) - H_ref.view(np.int32).astype(np.int64)).max())
-            d = O.reprojection_rmse_delta(H, H_ref, pairs[i].src).max()
-            print(f"[C5 pair {k}] {differ} of {H.size} float32 values differ by {ulp} ulp ({C5_ONE_ULP_PAIRS[k]}); rmse delta {d:.2e} px")
-            assert differ <= 2 and ulp == 1 and d < 1e-4
-            grids[i] = H_ref.copy()         # the warp below starts from the reference's grid
-            odd.append(k)
+        for i in range(16):
+            grids[i], n = reconcile(golden, "C5", lo + i, grids[i], g["H_sha256"][lo + i].tobytes(), pairs[i].src)
+            patched += n
         H = torch.stack([torch.from_numpy(x.reshape(-1, 9)) for x in grids]).to(dev)
         imgs = torch.stack([torch.from_numpy(p.img) for p in pairs]).to(dev)
         mw, mh = torch.from_numpy(p0.mesh[0].copy()).to(dev), torch.from_numpy(p0.mesh[1].copy()).to(dev)
@@ -144,32 +154,30 @@ def test_all_64_pairs_of_config_5_vs_reference(native, golden):
             assert sha(hinv_out[i].cpu().numpy().reshape(100, 100, 3, 3)) == g["Hinv_sha256"][lo + i].tobytes(), lo + i
             assert sha(out[i].cpu().numpy()) == g["warped_sha256"][lo + i].tobytes(), f"canvas of pair {lo + i} differs from the reference's"
         del pairs, imgs, out, H, hinv_out
-    assert len(odd) <= len(C5_ONE_ULP_PAIRS)
-
-
-C3_ONE_ULP_SEEDS = {}        # seed offset -> why (none found in round 6)
+    print(f"[C5 all] 64 grids, {patched} of {64 * 90000} float32 values one ulp from the reference's")
+    assert patched <= 4
 
 
 def test_sixteen_pairs_of_the_headline_configuration_vs_reference(native, golden):
     """Sixteen 4K pairs at the headline configuration (C3 with seed offsets 0..15: 2000 keypoints, 200 x 200 mesh) through the
     host-buffer entry points: the float32 grid, the in-place inverses and the canvas of each against the reference's own loops
-    (tests/golden/c3_seeds_sha.npz, make_golden.py C3seeds), by SHA-256 - 5.76 million more float32 values behind the observed
-    rate of test_all_64_pairs_of_config_5_vs_reference."""
+    (tests/golden/c3_seeds_sha.npz, make_golden.py C3seeds), by SHA-256 - 5.76 million more float32 values.  Two of them differ
+    from the reference's by one ulp (seed offsets 2 and 8) - in BOTH the engine's value is the exact answer's float32 and the
+    reference's float64 SVD is the one that is off (`reconcile`)."""
     g = golden("c3_seeds_sha")
     n = g["H_sha256"].shape[0]
-    odd = []
+    patched = 0
     for k in range(n):
         p = config_pair("C3", seed_offset=k)
         assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
         H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
-        if sha(H) != g["H_sha256"][k].tobytes():
-            odd.append(k)
-            continue            # (no reference grid to warp from: the grid's own fixture comes first, make_golden.py)
+        H, m = reconcile(golden, "C3", k, H, g["H_sha256"][k].tobytes(), p.src)
+        patched += m
         warped, hinv = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
         assert sha(hinv) == g["Hinv_sha256"][k].tobytes(), k
         assert sha(warped) == g["warped_sha256"][k].tobytes(), f"canvas of pair {k} differs from the reference's"
-    print(f"[C3 seeds] {n - len(odd)} of {n} grids bit-identical to the reference's; others: {odd}")
-    assert set(odd) <= set(C3_ONE_ULP_SEEDS), f"grids of seed offsets {odd} differ from the reference's: run tests/studies on them"
+    print(f"[C3 seeds] {n} grids, {patched} of {n * 360000} float32 values one ulp from the reference's")
+    assert patched <= 4
 
 
 @pytest.mark.parametrize("rows_per_wave,fast", [(1, 1), (4, 1), (2, 1), (5, 1), (6, 1), (8, 1), (4, 0), (0, 1)])
