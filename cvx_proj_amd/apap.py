@@ -236,8 +236,8 @@ class APAP:
 # ------------------------------------------------------------------------------------
 def save2mat(path, arr, name="sift_feature", prefix="./output/"):
     """Reference utils.py:68-70."""
-    import scipy.io
-    scipy.io.savemat(f"{prefix}{path}.mat", {name: arr})
+    from .utils import save2mat as _save
+    return _save(path, arr, name=name, prefix=prefix)
 
 
 def read_config(path):

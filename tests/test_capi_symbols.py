@@ -171,7 +171,9 @@ def test_the_command_line_needs_no_torch():
     import sys
     code = ("import sys; import cvx_proj_amd.apap as A; from cvx_proj_amd import _native; _native.lib(); "
             "import cvx_proj_amd.utils, cvx_proj_amd.baseline_stitch_test, cvx_proj_amd.synth, cvx_proj_amd.evaluate; "
-            "assert 'torch' not in sys.modules, 'torch was imported'; print('ok')")
+            "assert 'torch' not in sys.modules, 'torch was imported'; "
+            "import numpy as np, tempfile; A.save2mat('H31_apap', np.zeros((4, 9)), name='H', prefix=tempfile.mkdtemp() + '/'); "
+            "assert 'scipy' not in sys.modules, 'the .mat writer of the command imported scipy'; print('ok')")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-1500:]

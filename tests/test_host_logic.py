@@ -177,3 +177,25 @@ def test_c_prepare_in_the_dtype_of_the_keypoints(native, golden, tag):
     m = np.einsum("kri,krj->kij", r, r)
     want = np.stack([m[:, i, j] for i, j in MOMENT_INDEX], axis=1)
     assert np.array_equal(table[:, :30], want)
+
+
+def test_mat_writer_equals_scipy(tmp_path):
+    """cvx_proj_amd.utils.savemat_f64 - the `.mat` file of apap.py:264 without importing scipy - writes what scipy.io.savemat does,
+    byte for byte behind the creation time of the 128-byte header, and loads back through scipy."""
+    import re
+    import scipy.io
+    from cvx_proj_amd import utils as U
+    rng = np.random.default_rng(3)
+    for shape, name in (((400, 9), "H"), ((10000, 9), "H"), ((1, 1), "H"), ((7, 3), "sift_feature"), ((5, 2), "abcd"), ((5, 2), "abcde")):
+        a = rng.normal(size=shape)
+        for arr in (a, np.asfortranarray(a), a[::-1]):
+            U.save2mat("mine", arr, name=name, prefix=str(tmp_path) + "/")
+            scipy.io.savemat(str(tmp_path / "theirs.mat"), {name: arr})
+            mine, theirs = (tmp_path / "mine.mat").read_bytes(), (tmp_path / "theirs.mat").read_bytes()
+            assert mine[128:] == theirs[128:] and mine[116:128] == theirs[116:128]
+            strip = lambda b: re.sub(rb"Created on: .*", b"", b[:116].rstrip(b"\0"))      # noqa: E731
+            assert strip(mine) == strip(theirs)
+            assert np.array_equal(scipy.io.loadmat(str(tmp_path / "mine.mat"))[name], arr)
+    # anything that is not a real float64 matrix still goes to scipy
+    U.save2mat("ints", np.arange(6, dtype=np.int32).reshape(2, 3), name="k", prefix=str(tmp_path) + "/")
+    assert scipy.io.loadmat(str(tmp_path / "ints.mat"))["k"].dtype == np.int32
