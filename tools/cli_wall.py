@@ -33,8 +33,9 @@ def report(tag, args, env_extra=None):
     walls, last = [], None
     for _ in range(reps):
         w, st, mats = run(args, env_extra)
+        if not walls or w < min(walls):
+            last = st              # the break-down shown is the fastest run's own
         walls.append(w)
-        last = st
     p = last["pairs"]
     comp = sum(q["compute_ms"] for q in p)
     print(f"{tag:58s} wall {min(walls) * 1e3:7.0f} ms (min of {reps}; median {sorted(walls)[len(walls) // 2] * 1e3:.0f})  | python + numpy start "
