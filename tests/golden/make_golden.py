@@ -24,6 +24,7 @@ script is how they were made.
                 canvas; SHA-256 + every 64th row) and the SHA-256 of the in-place inverses (~1 min each)
     C3seeds     c3_seeds_sha: sixteen pairs of the headline configuration (seed offsets 0..15) through the reference's
                 local_homography and local_warp, in a process pool: SHA-256 of every grid, its in-place inverses and its canvas
+    C4seeds     c4_seeds_sha: four more 8K pairs (seed offsets 1..4 of C4) through the reference, grid / inverses / canvas by SHA-256
     C5all       c5_all_sha: ALL 64 pairs of config 5 through the reference's local_homography AND local_warp, in a process pool
                 (~1 minute of the reference's loops per pair): SHA-256 of every grid, of its in-place inverses and of every canvas
     f64pts      f64pts_ref: keypoints that are not float32 arrays (float64, one float64 set beside a float32 one, int64)
@@ -475,15 +476,16 @@ def c5_all(name="c5_all_sha.npz", pairs=64, workers=None):
     print(f"{name}: {pairs} pairs of C5, canvas {tuple(res[0][4])}")
 
 
-def seeds_all(cfg, name, pairs, workers=None):
-    """`pairs` pairs of `cfg` with seed offsets 0 .. pairs - 1 (offset 0 = the config's own pair) through the reference."""
+def seeds_all(cfg, name, pairs, workers=None, first=0):
+    """The pairs of `cfg` with seed offsets first .. pairs - 1 (offset 0 = the config's own pair) through the reference; row r of
+    the stored arrays is seed offset first + r."""
     import multiprocessing as mp
     workers = workers or max(1, os.cpu_count() or 2)
     with mp.get_context("spawn").Pool(workers, initializer=_c5_pool_init) as pool:
-        res = sorted(pool.imap_unordered(_cfg_pair, [(cfg, k) for k in range(pairs)]), key=lambda r: r[0])
+        res = sorted(pool.imap_unordered(_cfg_pair, [(cfg, k) for k in range(first, pairs)]), key=lambda r: r[0])
     np.savez_compressed(os.path.join(HERE, name), H_sha256=np.stack([r[1] for r in res]), Hinv_sha256=np.stack([r[2] for r in res]),
-                        warped_sha256=np.stack([r[3] for r in res]), final=res[0][4])
-    print(f"{name}: {pairs} pairs of {cfg}, canvas {tuple(res[0][4])}")
+                        warped_sha256=np.stack([r[3] for r in res]), final=res[0][4], seeds=np.array([r[0] for r in res]))
+    print(f"{name}: {len(res)} pairs of {cfg}, canvas {tuple(res[0][4])}")
 
 
 def main():
@@ -491,6 +493,12 @@ def main():
         # sixteen 4K pairs at the headline configuration (seed offsets 0..15; offset 0 is c3_ref's pair): ~1.5 minutes of the
         # reference's loops each
         seeds_all("C3", "c3_seeds_sha.npz", 16)
+        if len(sys.argv) == 2:
+            return
+    if "C4seeds" in sys.argv[1:]:
+        # four more 8K pairs (seed offsets 1..4 of C4; offset 0 is c4_ref_rows8's pair): ~10 minutes of the reference's loops
+        # and 6.4 GB of its weight tensor each, hence four workers
+        seeds_all("C4", "c4_seeds_sha.npz", 5, workers=4, first=1)
         if len(sys.argv) == 2:
             return
     if "C5all" in sys.argv[1:]:

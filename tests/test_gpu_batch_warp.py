@@ -180,6 +180,26 @@ def test_sixteen_pairs_of_the_headline_configuration_vs_reference(native, golden
     assert patched <= 4
 
 
+def test_four_more_8k_pairs_vs_reference(native, golden):
+    """Four more pairs at BASELINE config 4's size (8K, 5000 keypoints, 400 x 400 mesh: C4 with seed offsets 1..4) through the
+    host-buffer entry points: grid, in-place inverses and canvas against the reference's own loops (tests/golden/c4_seeds_sha.npz,
+    make_golden.py C4seeds: ~10 minutes of the reference per pair), by SHA-256 - 5.76 million more float32 values."""
+    g = golden("c4_seeds_sha")
+    patched = 0
+    for r, k in enumerate(int(v) for v in g["seeds"]):
+        p = config_pair("C4", seed_offset=k)
+        assert (p.final_w, p.final_h, p.off_x, p.off_y) == tuple(int(v) for v in g["final"])
+        H, _ = native.local_homography(p.src, p.dst, p.vertices, p.gamma, p.sigma, want_weights=False)
+        H, m = reconcile(golden, "C4", k, H, g["H_sha256"][r].tobytes(), p.src[:512])
+        patched += m
+        warped, hinv = native.local_warp(p.img, H, p.mesh[0], p.mesh[1], p.final_w, p.final_h, p.off_x, p.off_y)
+        assert sha(hinv) == g["Hinv_sha256"][r].tobytes(), k
+        assert sha(warped) == g["warped_sha256"][r].tobytes(), f"canvas of pair {k} differs from the reference's"
+        del p, warped
+    print(f"[C4 seeds] {len(g['seeds'])} grids, {patched} of {len(g['seeds']) * 1440000} float32 values one ulp from the reference's")
+    assert patched <= 4
+
+
 @pytest.mark.parametrize("rows_per_wave,fast", [(1, 1), (4, 1), (2, 1), (5, 1), (6, 1), (8, 1), (4, 0), (0, 1)])
 def test_batched_warp_equals_per_pair_launches(native, rows_per_wave, fast):
     """Every kernel form (float32-estimate strips, all-float64 strips, flat order) with grid.z = pair: the canvases
