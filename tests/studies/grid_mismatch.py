@@ -20,14 +20,17 @@ FIXTURE = os.path.join(ROOT, "tests", "golden", "one_ulp_cases.npz")
 cases = []      # (cfg, seed offset, mesh row, mesh column, entry row, entry column, reference's float32, exact answer's float32)
 cfg = str(z["cfg"]) if "cfg" in z.files else "C5"
 listed = "cfg" in z.files          # engine_grids.py stores the listed pairs only, in the order of `bad`
+only = [int(v) for v in sys.argv[2:]]          # optional: the seed offsets to look at (the others in the file are skipped)
 for n_k, k in enumerate(z["bad"]):
+    if only and int(k) not in only:
+        continue
     p = config_pair(cfg, with_image=False, seed_offset=int(k))
     eng = ref_apap.APAP(p.gamma, p.sigma, [p.final_w, p.final_h], [p.off_x, p.off_y])
     H_ref, _ = eng.local_homography(p.src, p.dst, p.vertices)
     H_gpu = z["grids"][n_k if listed else int(k)]
     diff = np.argwhere(H_ref != H_gpu)
     ulp = np.abs(H_ref.view(np.int32).astype(np.int64) - H_gpu.view(np.int32).astype(np.int64))
-    d = O.reprojection_rmse_delta(H_gpu, H_ref, p.src)
+    d = O.reprojection_rmse_delta(H_gpu, H_ref, p.src[:256])
     print(f"{cfg} pair {k}: {len(diff)} of {H_ref.size} float32 values differ, max {ulp.max()} ulp, rmse delta max {d.max():.3e} px")
     H_fast, _ = O.local_homography_fast(p.src, p.dst, p.vertices, p.gamma, p.sigma)
     print(f"   oracle (eigh of the normal matrix) vs reference: {int((H_fast != H_ref).sum())} differ; vs engine: {int((H_fast != H_gpu).sum())} differ")
@@ -41,6 +44,13 @@ for n_k, k in enumerate(z["bad"]):
 # tests/golden/one_ulp_cases.npz: where the reference's grid and the engine's differ - the REFERENCE's value at that position and
 # the exact answer's float32 (60-digit SVD of the reference's own matrix).  The tests patch the engine's grid with the reference's
 # value at exactly these positions and then demand the reference's SHA-256: the fixture holds no engine output.
+if only:       # a partial run (several in parallel: a C4 pair is 8 minutes and 7 GB of the reference): the cases go beside the input ...
+    np.save(sys.argv[1] + f".cases_{'_'.join(map(str, only))}.npy", np.array(cases, dtype=object), allow_pickle=True)
+    cases = []
+else:          # ... and a run over all pairs of the file (or over one that has none left to look at) merges them into the fixture
+    import glob
+    for path in sorted(glob.glob(sys.argv[1] + ".cases_*.npy")):
+        cases += [tuple(c) for c in np.load(path, allow_pickle=True)]
 if cases:
     old = []
     if os.path.exists(FIXTURE):
