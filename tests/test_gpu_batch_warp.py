@@ -183,7 +183,8 @@ def test_sixteen_pairs_of_the_headline_configuration_vs_reference(native, golden
 def test_four_more_8k_pairs_vs_reference(native, golden):
     """Four more pairs at BASELINE config 4's size (8K, 5000 keypoints, 400 x 400 mesh: C4 with seed offsets 1..4) through the
     host-buffer entry points: grid, in-place inverses and canvas against the reference's own loops (tests/golden/c4_seeds_sha.npz,
-    make_golden.py C4seeds: ~10 minutes of the reference per pair), by SHA-256 - 5.76 million more float32 values."""
+    make_golden.py C4seeds: ~10 minutes of the reference per pair), by SHA-256 - 5.76 million more float32 values, four of them
+    one ulp from the reference's (`reconcile`: one where the reference's SVD is off, three where the engine's rounding is)."""
     g = golden("c4_seeds_sha")
     patched = 0
     for r, k in enumerate(int(v) for v in g["seeds"]):
