@@ -483,18 +483,16 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
     // for the vertex registers lands inside the step loop as vmcnt(0) and also waits for
     // the NEXT chunk's prefetch, which is meant to fly during the MFMAs.
     __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-    for (int c = 0; c < nchunks; ++c) {
+    // Whole chunks first, in a loop with ONE exit (with the partial chunk's early `break` inside it the compiler kept a third
+    // set of accumulator registers and more copies between them; the copies that are left - 32 v_accvgpr_mov per chunk, the
+    // accumulators out to a second set and back at the loop's edge - are hipcc's handling of an AGPR phi and did not yield to
+    // unrolling: round 6, 24-sum form 135.4 -> 132.7 us, the default within the noise); a partial last chunk after it runs only the steps that hold keypoints (its missing rows are zero and would add +0 to
+    // every sum, at the full price of a step: C3's 1000 keypoints per split are 15 chunks and 10 steps of the 16th - 2.3 % of
+    // the kernel).  Same MFMAs in the same order as ever: identical sums.
+    const int nfull = (p_end - p_begin) / kChunk;
+    for (int c = 0; c < nfull; ++c) {
         if (c + 1 < nchunks) load_chunk(c + 1);
         const unsigned char *buf = lds[c & 1];
-        // A partial last chunk runs only the steps that hold keypoints (its missing rows are zero and would
-        // add +0 to every sum, at the full price of a step: C3's 1000 keypoints per split are 15 chunks
-        // and 10 steps of the 16th - 2.3 % of the kernel).  Same MFMAs in the same order: identical sums.
-        const int steps_here = min(kChunk / 4, (p_end - p_begin - c * kChunk + 3) >> 2);
-        if (steps_here < kChunk / 4) {
-            for (int s1 = 0; s1 < steps_here; ++s1)
-                accumulate(weight(buf + off_xy + 1024 * s1), buf + off_b0 + 1024 * s1, buf + off_b1 + 1024 * s1);
-            break;   // fewer than 64 keypoints left: this was the last chunk
-        }
         // The weights of g steps first, then their 2 g MFMAs back to back: g times fewer MFMA <-> VALU
         // transitions (~10 issue cycles each, profiles/r02_coexec.txt) and g independent weight chains
         // for the scheduler.  Same MFMAs in the same order per accumulator: bit-identical sums.
@@ -513,6 +511,12 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
         }
         if (c + 1 < nchunks) store_chunk((c + 1) & 1);
         __syncthreads();
+    }
+    if (nfull < nchunks) {      // the partial last chunk (staged and published by the loop's last pass, or by the prologue)
+        const unsigned char *buf = lds[nfull & 1];
+        const int steps_here = (p_end - p_begin - nfull * kChunk + 3) >> 2;
+        for (int s1 = 0; s1 < steps_here; ++s1)
+            accumulate(weight(buf + off_xy + 1024 * s1), buf + off_b0 + 1024 * s1, buf + off_b1 + 1024 * s1);
     }
 
     // D layout of v_mfma_f64_16x16x4_f64: register i of lane l is D[row = (l >> 4) + 4 i][col = l & 15],
