@@ -505,21 +505,8 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
 #pragma unroll
             for (int g = 0; g < 8; ++g) w2[g] = weight(buf + off_xy + 1024 * (s0 + g));
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kM24) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) accumulate(w2[g], buf + off_b0 + 1024 * (s0 + g), buf + off_b1 + 1024 * (s0 + g));
-            } else {
-                // the group's 8 MFMAs on one accumulator back to back, then the 8 on the other: a chain on ONE accumulator keeps it
-                // inside the matrix pipe (tools/i8_coexec.hip: 74 cycles per dependent 16x16x4 against ~105 when accumulators
-                // alternate).  Each accumulator still takes its steps in the same order: the same sums, bit for bit.
-#pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[g], *reinterpret_cast<const double *>(buf + off_b0 + 1024 * (s0 + g)), acc0, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);      // (or the scheduler interleaves the two chains again)
-#pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(w2[g], *reinterpret_cast<const double *>(buf + off_b1 + 1024 * (s0 + g)), acc1, 0, 0, 0);
-            }
+            for (int g = 0; g < 8; ++g) accumulate(w2[g], buf + off_b0 + 1024 * (s0 + g), buf + off_b1 + 1024 * (s0 + g));
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 1 < nchunks) store_chunk((c + 1) & 1);
