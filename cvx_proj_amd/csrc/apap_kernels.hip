@@ -483,12 +483,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_assemble_mfma(const double *__r
     // for the vertex registers lands inside the step loop as vmcnt(0) and also waits for
     // the NEXT chunk's prefetch, which is meant to fly during the MFMAs.
     __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-    // Whole chunks first, in a loop with ONE exit (with the partial chunk's early `break` inside it the compiler kept a third
-    // set of accumulator registers and more copies between them; the copies that are left - 32 v_accvgpr_mov per chunk, the
-    // accumulators out to a second set and back at the loop's edge - are hipcc's handling of an AGPR phi and did not yield to
-    // unrolling: round 6, 24-sum form 135.4 -> 132.7 us, the default within the noise); a partial last chunk after it runs only the steps that hold keypoints (its missing rows are zero and would add +0 to
-    // every sum, at the full price of a step: C3's 1000 keypoints per split are 15 chunks and 10 steps of the 16th - 2.3 % of
-    // the kernel).  Same MFMAs in the same order as ever: identical sums.
+    // Whole chunks first, in a loop with ONE exit (round 6: with the partial chunk's early `break` inside it the compiler kept more
+    // copies of the accumulators); a partial last chunk after it runs only the steps that hold keypoints (its missing rows are
+    // zero and would add +0 to every sum, at the full price of a step: C3's 1000 keypoints per split are 15 chunks and 10 steps
+    // of the 16th - 2.3 % of the kernel).  Same MFMAs in the same order as ever: identical sums.
+    // (Also round 6, not kept: ONE block of 8 waves running both keypoint splits of its 64 cells and adding them through LDS
+    // before it stores one slab - bit-identical, K2 8.4 -> 7.2 us, but K1 147.5 -> 173 us: eight waves on one barrier per
+    // chunk, two 68 KB blocks per CU.  profiles/r06_k1_compiler.txt.)
     const int nfull = (p_end - p_begin) / kChunk;
     for (int c = 0; c < nfull; ++c) {
         if (c + 1 < nchunks) load_chunk(c + 1);
